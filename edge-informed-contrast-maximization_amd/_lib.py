@@ -1,0 +1,89 @@
+"""ctypes binding of libeincm_hip.so (C-ABI: include/eincm.h).  No CPU fallback: a missing library raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libeincm_hip.so')
+
+MAX_REFS = 16
+N_STAGES = 10
+STAGE_NAMES = ('clear', 'theta', 'splat', 'stats', 'imgrad', 'gather', 'tv', 'project', 'final', 'copy')
+
+OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_NONFINITE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+CONTRAST_GRAD_MAG, CONTRAST_VARIANCE = 0, 1
+METHODS = {'linear': 0, 'bilinear': 0, 'triangle': 0, 'lanczos3': 1, 'lanczos5': 2, 'cubic': 3, 'bicubic': 3}
+PF_FULL_AUX = 1
+CF_TIMING = 1
+
+
+class Params(C.Structure):
+    _fields_ = [('alpha', C.c_double), ('beta', C.c_double), ('gamma', C.c_double), ('delta', C.c_double),
+                ('cur_pyr_lvl', C.c_int32), ('method', C.c_int32), ('contrast_kind', C.c_int32), ('flags', C.c_uint32)]
+
+
+class Aux(C.Structure):
+    _fields_ = [('final_loss', C.c_double), ('mean_rel_corr', C.c_double), ('mean_rel_contrast', C.c_double),
+                ('mean_rel_iwe_divergence', C.c_double), ('theta_total_variation', C.c_double)]
+
+
+_A = C.c_double * MAX_REFS
+
+
+class ObjectivesOut(C.Structure):
+    _fields_ = [('n_refs', C.c_int32), ('_pad', C.c_int32),
+                ('correlations', _A), ('zero_correlations', _A), ('rel_correlations', _A),
+                ('contrasts', _A), ('zero_contrast', C.c_double), ('rel_contrasts', _A),
+                ('theta_total_variation', C.c_double), ('theta_divergence', C.c_double),
+                ('iwe_divergences', _A), ('zero_iwe_divergence', C.c_double), ('rel_iwe_divergences', _A),
+                ('flow_warp_losses', _A), ('multi_ref_weights', _A), ('variances', _A), ('zero_variance', C.c_double)]
+
+
+class Timings(C.Structure):
+    _fields_ = [('ms', C.c_float * N_STAGES), ('total_ms', C.c_float)]
+
+
+# every symbol include/eincm.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+SIGNATURES = [
+    ('eincm_abi_version', C.c_int, []),
+    ('eincm_last_error', C.c_char_p, [_P]),
+    ('eincm_create', _P, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint32]),
+    ('eincm_destroy', None, [_P]),
+    ('eincm_set_windows', C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int16),
+                                    C.POINTER(C.c_int16), _D, _D, _D]),
+    ('eincm_loss_grad', C.c_int, [_P, _D, C.c_int, C.c_int, C.POINTER(Params), _D, _D, C.POINTER(Aux)]),
+    ('eincm_handover_loss_grad', C.c_int, [_P, _D, _D, _D, C.c_int, C.c_int, C.POINTER(Params), _D, _D]),
+    ('eincm_objectives', C.c_int, [_P, _D, C.POINTER(ObjectivesOut)]),
+    ('eincm_get_iwes', C.c_int, [_P, C.POINTER(C.c_float)]),
+    ('eincm_get_zero_iwe', C.c_int, [_P, C.POINTER(C.c_float)]),
+    ('eincm_get_image_grad', C.c_int, [_P, C.POINTER(C.c_float)]),
+    ('eincm_get_scaled_theta', C.c_int, [_P, _D]),
+    ('eincm_multi_ref_weights', C.c_int, [C.c_int, _D]),
+    ('eincm_resample_matrix', C.c_int, [C.c_int, C.c_int, C.c_int, _D]),
+    ('eincm_get_timings', C.c_int, [_P, C.POINTER(Timings)]),
+]
+
+_lib = None
+
+
+class EincmLibraryMissing(ImportError):
+    pass
+
+
+def load():
+    """Load libeincm_hip.so (built in-tree by __graft_entry__.build()).  Raises if absent: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EincmLibraryMissing(
+            f'{LIB_PATH} not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950). This engine has no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SIGNATURES:
+        fn = getattr(lib, name)           # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,737 @@
+// eincm_api.hip — host engine behind the C-ABI of include/eincm.h (libeincm_hip.so, gfx950 only).
+//
+// Host responsibilities (everything else runs in the kernels of eincm_kernels.hip.h):
+//   - own the HBM layout of a batch of event windows (see DESIGN.md "Data layout in HBM")
+//   - bin events by 32x32 source tile once per window and cut the bins into work items
+//   - build the scale_and_translate weight matrices (theta_utils.py:25-35) for the current theta shape
+//   - launch the evaluation sequence on one stream and hand (value, grad, aux) back as float64
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "eincm.h"
+#include "eincm_kernels.hip.h"
+
+using namespace eincm;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct eincm_ctx {
+    int device = 0;
+    int H = 0, W = 0, maxR = 0, maxB = 0;
+    int64_t maxN = 0;
+    uint32_t cflags = 0;
+    int chunk = 2048;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // staged batch
+    bool staged = false;
+    Geom g{};
+    int n_items = 0;
+    int64_t n_events = 0;
+    std::vector<int64_t> win_events;
+
+    // device buffers
+    uint32_t* d_xy = nullptr;      // (maxN) x | y<<16, binned
+    double* d_t = nullptr;         // (maxN)
+    Item* d_items = nullptr;       // (max_items)
+    int64_t max_items = 0;
+    float* d_edges = nullptr;      // (B,R,H,W)
+    double* d_edge_ts = nullptr;   // (B,R)
+    float* d_iwe = nullptr;        // (B,R,H,W)
+    float* d_G = nullptr;          // (B,R,H,W)
+    float* d_zero_iwe = nullptr;   // (B,H,W)
+    double* d_Theta = nullptr;     // (B,H,W,2)
+    double* d_theta_in = nullptr;  // (B,H,W,2) capacity (coarse uses a prefix)
+    float* d_gTheta = nullptr;     // (B,H,W,2)
+    double* d_tvg = nullptr;       // (B,H,W,2)
+    uint8_t* d_mask = nullptr;     // (B,H,W)
+    double* d_tmm = nullptr;       // (B,ntiles,4)
+    StatPart* d_parts = nullptr;   // (B,R,ntiles)
+    double* d_divparts = nullptr;  // (B,R,ntiles)
+    double* d_tvparts = nullptr;   // (B,ntiles,3)
+    WinConst* d_wc = nullptr;      // (B)
+    OutScal* d_outs = nullptr;     // (B)
+    double* d_gth = nullptr;       // (2,B,maxcoarse) main | tv accumulators for coarse theta
+    double* d_grad = nullptr;      // (B,H,W,2) capacity
+    double* d_AH = nullptr; double* d_AW = nullptr;     // (H,h) (W,w) capacity H*H, W*W? -> sized on demand
+    int2* d_rowtap = nullptr; int2* d_coltap = nullptr;
+    size_t AH_cap = 0, AW_cap = 0;
+    int cur_h = -1, cur_w = -1, cur_method = -1;
+    int64_t coarse_cap = 0;        // doubles per window in d_gth halves
+
+    // pinned host staging
+    double* h_theta = nullptr;     // (B,H,W,2) capacity
+    double* h_grad = nullptr;
+    OutScal* h_outs = nullptr;
+    WinConst* h_wc = nullptr;
+
+    // timing
+    hipEvent_t ev[EINCM_N_STAGES + 1][2];
+    bool ev_used[EINCM_N_STAGES + 1];
+    bool have_events = false;
+    eincm_timings last_t{};
+
+    // last eval bookkeeping
+    bool have_eval = false;
+};
+
+namespace {
+
+int fail(eincm_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail((c), EINCM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+template <typename T> hipError_t dalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)); }
+
+// ---------------------------------------------------------------------------------------------
+// jax.image.scale_and_translate per-axis weight matrix (S7; theta_utils.py:25-35), fp64 on the host.
+// A is (n_out, n_in): out = A @ in.
+// ---------------------------------------------------------------------------------------------
+double kern_eval(int method, double x) {
+    switch (method) {
+        case EINCM_METHOD_BILINEAR: return std::max(0.0, 1.0 - std::fabs(x));
+        case EINCM_METHOD_LANCZOS3:
+        case EINCM_METHOD_LANCZOS5: {
+            const double radius = (method == EINCM_METHOD_LANCZOS3) ? 3.0 : 5.0;
+            if (x > radius) return 0.0;
+            if (!(x > 1e-3)) return 1.0;
+            const double y = radius * std::sin(M_PI * x) * std::sin(M_PI * x / radius);
+            return y / (M_PI * M_PI * x * x);
+        }
+        case EINCM_METHOD_CUBIC: {
+            if (x >= 2.0) return 0.0;
+            if (x >= 1.0) return ((-0.5 * x + 2.5) * x - 4.0) * x + 2.0;
+            return ((1.5 * x - 2.5) * x) * x + 1.0;
+        }
+    }
+    return 0.0;
+}
+
+void resample_matrix(int n_in, int n_out, int method, std::vector<double>& A) {
+    A.assign((size_t)n_out * n_in, 0.0);
+    const double scale = (double)n_out / (double)n_in;
+    const double inv_scale = 1.0 / scale;
+    const double kernel_scale = std::max(inv_scale, 1.0);
+    const double thresh = 1000.0 * 1.1920928955078125e-07;   // 1000 * float32 eps
+    for (int o = 0; o < n_out; ++o) {
+        const double sample_f = ((double)o + 0.5) * inv_scale - 0.5;
+        double total = 0.0;
+        for (int i = 0; i < n_in; ++i) {
+            const double x = std::fabs(sample_f - (double)i) / kernel_scale;
+            const double wgt = kern_eval(method, x);
+            A[(size_t)o * n_in + i] = wgt;
+            total += wgt;
+        }
+        const bool inside = (sample_f >= -0.5) && (sample_f <= (double)n_in - 0.5);
+        for (int i = 0; i < n_in; ++i) {
+            double& a = A[(size_t)o * n_in + i];
+            a = (std::fabs(total) > thresh) ? a / (total != 0.0 ? total : 1.0) : 0.0;
+            if (!inside) a = 0.0;
+        }
+    }
+}
+
+void multi_ref_weights(int R, double* w) {
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) {
+        // np.linspace(-1.5, 1.5, R): start + r*step with step = 3/(R-1); R == 1 -> [-1.5]
+        const double x = (R > 1) ? (-1.5 + (double)r * (3.0 / (double)(R - 1))) : -1.5;
+        w[r] = std::exp(-0.5 * x * x) / std::sqrt(2.0 * M_PI);
+        s += w[r];
+    }
+    for (int r = 0; r < R; ++r) w[r] /= s;
+}
+
+void free_all(eincm_ctx* c) {
+    auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_edges); F(c->d_edge_ts); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
+    F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
+    F(c->d_divparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); F(c->d_gth); F(c->d_grad); F(c->d_AH); F(c->d_AW);
+    F(c->d_rowtap); F(c->d_coltap);
+    auto FH = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
+    FH(c->h_theta); FH(c->h_grad); FH(c->h_outs); FH(c->h_wc);
+    if (c->have_events) {
+        for (int i = 0; i <= EINCM_N_STAGES; ++i) { (void)hipEventDestroy(c->ev[i][0]); (void)hipEventDestroy(c->ev[i][1]); }
+        c->have_events = false;
+    }
+    if (c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
+}
+
+struct StageTimer {
+    eincm_ctx* c; int stage; bool on;
+    StageTimer(eincm_ctx* c_, int s) : c(c_), stage(s), on((c_->cflags & EINCM_CF_TIMING) != 0) {
+        if (on) { (void)hipEventRecord(c->ev[stage][0], c->stream); }
+    }
+    ~StageTimer() {
+        if (on) { (void)hipEventRecord(c->ev[stage][1], c->stream); c->ev_used[stage] = true; }
+    }
+};
+
+int ensure_resample(eincm_ctx* c, int h, int w, int method) {
+    if (c->cur_h == h && c->cur_w == w && c->cur_method == method) return EINCM_OK;
+    const int H = c->H, W = c->W;
+    std::vector<double> AH, AW;
+    resample_matrix(h, H, method, AH);
+    resample_matrix(w, W, method, AW);
+    std::vector<int2> rt(H), ct(W);
+    for (int y = 0; y < H; ++y) {
+        int lo = h, hi = 0;
+        for (int i = 0; i < h; ++i) if (AH[(size_t)y * h + i] != 0.0) { lo = std::min(lo, i); hi = std::max(hi, i + 1); }
+        if (lo >= hi) { lo = 0; hi = 0; }
+        rt[y] = make_int2(lo, hi);
+    }
+    for (int x = 0; x < W; ++x) {
+        int lo = w, hi = 0;
+        for (int j = 0; j < w; ++j) if (AW[(size_t)x * w + j] != 0.0) { lo = std::min(lo, j); hi = std::max(hi, j + 1); }
+        if (lo >= hi) { lo = 0; hi = 0; }
+        ct[x] = make_int2(lo, hi);
+    }
+    if (AH.size() > c->AH_cap) {
+        if (c->d_AH) { (void)hipFree(c->d_AH); c->d_AH = nullptr; }
+        HIPCHK(c, dalloc(&c->d_AH, AH.size()));
+        c->AH_cap = AH.size();
+    }
+    if (AW.size() > c->AW_cap) {
+        if (c->d_AW) { (void)hipFree(c->d_AW); c->d_AW = nullptr; }
+        HIPCHK(c, dalloc(&c->d_AW, AW.size()));
+        c->AW_cap = AW.size();
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_AH, AH.data(), AH.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_AW, AW.data(), AW.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_rowtap, rt.data(), rt.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_coltap, ct.data(), ct.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // host vectors go out of scope
+    c->cur_h = h; c->cur_w = w; c->cur_method = method;
+    return EINCM_OK;
+}
+
+// Launch the forward half: theta -> Theta -> IWE stack -> image statistics.
+// theta must already be in d_theta_in (identity: (B,H,W,2); else (B,h,w,2)).
+int launch_forward(eincm_ctx* c, int h, int w, bool identity) {
+    const Geom& g = c->g;
+    const size_t img = (size_t)g.H * g.W;
+    {
+        StageTimer t(c, EINCM_STAGE_CLEAR);
+        HIPCHK(c, hipMemsetAsync(c->d_iwe, 0, (size_t)g.B * g.R * img * sizeof(float), c->stream));
+    }
+    {
+        StageTimer t(c, EINCM_STAGE_THETA);
+        hipLaunchKernelGGL(k_theta, dim3(g.ntiles, g.B), dim3(NT), 0, c->stream, g, h, w, identity ? 1 : 0,
+                           c->d_theta_in, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_Theta, c->d_tmm);
+    }
+    {
+        StageTimer t(c, EINCM_STAGE_SPLAT);
+        hipLaunchKernelGGL(k_splat, dim3(c->n_items, g.R), dim3(NT), WIN_CAP * sizeof(float), c->stream, g, c->d_items,
+                           c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe);
+    }
+    {
+        StageTimer t(c, EINCM_STAGE_STATS);
+        hipLaunchKernelGGL(k_stats, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_edges, c->d_parts);
+    }
+    HIPCHK(c, hipGetLastError());
+    return EINCM_OK;
+}
+
+int collect_timings(eincm_ctx* c) {
+    if (!(c->cflags & EINCM_CF_TIMING)) return EINCM_OK;
+    memset(&c->last_t, 0, sizeof c->last_t);
+    for (int s = 0; s < EINCM_N_STAGES; ++s) {
+        if (!c->ev_used[s]) continue;
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]));
+        c->last_t.ms[s] = ms;
+    }
+    if (c->ev_used[EINCM_N_STAGES]) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[EINCM_N_STAGES][0], c->ev[EINCM_N_STAGES][1]));
+        c->last_t.total_ms = ms;
+    }
+    return EINCM_OK;
+}
+
+// The whole evaluation.  theta_host: (B,h,w,2) doubles (already validated).
+int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_params* p,
+             double* value, double* grad, eincm_aux* aux, bool for_constants) {
+    const Geom& g = c->g;
+    const bool identity = (h == g.H && w == g.W);
+    const size_t img = (size_t)g.H * g.W;
+    const size_t nth = (size_t)h * w * 2;
+    const bool want_grad = (grad != nullptr);
+    const bool full_aux = (p->flags & EINCM_PF_FULL_AUX) != 0;
+    if (p->delta != 0.0 && want_grad)
+        return fail(c, EINCM_ERR_UNSUPPORTED, "gradient of the IWE-divergence term (delta != 0) is not implemented; "
+                                               "the reference keeps delta = 0 (configs/main.yaml:19)");
+    if (p->contrast_kind != EINCM_CONTRAST_GRAD_MAG && p->contrast_kind != EINCM_CONTRAST_VARIANCE)
+        return fail(c, EINCM_ERR_ARG, "contrast_kind %d unknown", p->contrast_kind);
+    if (!identity) {
+        if ((int64_t)nth > c->coarse_cap)
+            return fail(c, EINCM_ERR_ARG, "theta (%d,%d,2) exceeds the coarse capacity of this context", h, w);
+        int rc = ensure_resample(c, h, w, p->method);
+        if (rc) return rc;
+    }
+    for (int s = 0; s <= EINCM_N_STAGES; ++s) c->ev_used[s] = false;
+    const bool timing = (c->cflags & EINCM_CF_TIMING) != 0;
+    if (timing) { (void)hipEventRecord(c->ev[EINCM_N_STAGES][0], c->stream); }
+
+    EvalParams ep{};
+    ep.alpha = p->alpha; ep.beta = p->beta; ep.gamma = p->gamma; ep.delta = p->delta;
+    ep.cur_pyr_lvl = p->cur_pyr_lvl; ep.contrast_kind = p->contrast_kind;
+    ep.want_div = (full_aux || p->delta != 0.0) ? 1 : 0;
+    ep.want_tv = ((p->cur_pyr_lvl <= 0) && (p->gamma != 0.0 || full_aux)) ? 1 : 0;
+    ep.use_tv_grad = (ep.want_tv && p->gamma != 0.0 && want_grad) ? 1 : 0;
+    ep.h = h; ep.w = w; ep.identity = identity ? 1 : 0;
+
+    {
+        StageTimer t(c, EINCM_STAGE_COPY);
+        memcpy(c->h_theta, theta_host, (size_t)g.B * nth * sizeof(double));
+        HIPCHK(c, hipMemcpyAsync(c->d_theta_in, c->h_theta, (size_t)g.B * nth * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    int rc = launch_forward(c, h, w, identity);
+    if (rc) return rc;
+
+    if (ep.want_div) {
+        hipLaunchKernelGGL(k_div, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_parts, c->d_divparts);
+    }
+    if (ep.want_tv) {
+        StageTimer t(c, EINCM_STAGE_TV);
+        hipLaunchKernelGGL(k_tv, dim3(g.ntiles, g.B), dim3(NT), 0, c->stream, g, c->d_Theta, c->d_mask, c->d_tvg,
+                           c->d_tvparts, full_aux ? 1 : 0);
+    }
+    if (want_grad) {
+        {
+            StageTimer t(c, EINCM_STAGE_IMGRAD);
+            hipLaunchKernelGGL(k_imgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, ep, c->d_iwe, c->d_edges,
+                               c->d_parts, c->d_wc, c->d_G);
+        }
+        {
+            StageTimer t(c, EINCM_STAGE_GATHER);
+            HIPCHK(c, hipMemsetAsync(c->d_gTheta, 0, (size_t)g.B * img * 2 * sizeof(float), c->stream));
+            hipLaunchKernelGGL(k_gather, dim3(c->n_items, g.R), dim3(NT), (WIN_CAP + TS * TS * 2) * sizeof(float), c->stream,
+                               g, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta);
+        }
+        if (!identity) {
+            StageTimer t(c, EINCM_STAGE_PROJECT);
+            HIPCHK(c, hipMemsetAsync(c->d_gth, 0, (size_t)2 * g.B * c->coarse_cap * sizeof(double), c->stream));
+            // accumulators are laid out (B, nth) inside each half
+            hipLaunchKernelGGL(k_project, dim3(g.ntiles, g.B, ep.use_tv_grad ? 2 : 1), dim3(NT), 0, c->stream, g, h, w,
+                               c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_gTheta, c->d_tvg, c->d_gth,
+                               c->d_gth + (size_t)g.B * c->coarse_cap);
+        }
+    }
+    {
+        StageTimer t(c, EINCM_STAGE_FINAL);
+        hipLaunchKernelGGL(k_final, dim3(g.B), dim3(NT), 0, c->stream, g, ep, c->d_parts, c->d_divparts, c->d_tvparts,
+                           c->d_tmm, c->d_wc, c->d_gth, c->d_gth + (size_t)g.B * c->coarse_cap, c->d_outs, c->d_grad,
+                           want_grad ? 1 : 0);
+        if (want_grad && identity) {
+            hipLaunchKernelGGL(k_final_dense, dim3(256, g.B), dim3(NT), 0, c->stream, g, ep.use_tv_grad, c->d_gTheta,
+                               c->d_tvg, c->d_outs, c->d_grad);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal), hipMemcpyDeviceToHost, c->stream));
+    if (want_grad)
+        HIPCHK(c, hipMemcpyAsync(c->h_grad, c->d_grad, (size_t)g.B * nth * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (timing) { (void)hipEventRecord(c->ev[EINCM_N_STAGES][1], c->stream); c->ev_used[EINCM_N_STAGES] = true; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = collect_timings(c);
+    if (rc) return rc;
+    c->have_eval = true;
+    (void)for_constants;
+
+    bool nonfinite = false;
+    for (int b = 0; b < g.B; ++b) {
+        const OutScal& o = c->h_outs[b];
+        if (value) value[b] = o.value;
+        if (aux) {
+            aux[b].final_loss = o.value;
+            aux[b].mean_rel_corr = o.mean_rel_corr;
+            aux[b].mean_rel_contrast = o.mean_rel_contrast;
+            aux[b].mean_rel_iwe_divergence = o.mean_rel_div;
+            aux[b].theta_total_variation = o.tv;
+        }
+        if (o.nonfinite != 0.0) nonfinite = true;
+    }
+    if (want_grad) {
+        memcpy(grad, c->h_grad, (size_t)g.B * nth * sizeof(double));
+        const size_t n = (size_t)g.B * nth;
+        for (size_t i = 0; i < n && !nonfinite; ++i)
+            if (!std::isfinite(grad[i])) nonfinite = true;
+    }
+    if (nonfinite) return fail(c, EINCM_ERR_NONFINITE, "loss or gradient is not finite");
+    return EINCM_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+int eincm_abi_version(void) { return EINCM_ABI_VERSION; }
+
+const char* eincm_last_error(const eincm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int eincm_multi_ref_weights(int n_refs, double* w) {
+    if (n_refs < 1 || n_refs > EINCM_MAX_REFS || !w) return EINCM_ERR_ARG;
+    multi_ref_weights(n_refs, w);
+    return EINCM_OK;
+}
+
+int eincm_resample_matrix(int n_in, int n_out, int method, double* A) {
+    if (n_in < 1 || n_out < 1 || !A || method < 0 || method > EINCM_METHOD_CUBIC) return EINCM_ERR_ARG;
+    std::vector<double> M;
+    resample_matrix(n_in, n_out, method, M);
+    memcpy(A, M.data(), M.size() * sizeof(double));
+    return EINCM_OK;
+}
+
+eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows, int64_t max_events_total, uint32_t flags) {
+    if (H < 3 || W < 3 || H > 32767 || W > 32767 || max_refs < 1 || max_refs > EINCM_MAX_REFS || max_windows < 1 ||
+        max_events_total < 1 || max_events_total > (int64_t)2000000000) {
+        fail(nullptr, EINCM_ERR_ARG, "eincm_create: bad argument (H=%d W=%d max_refs=%d max_windows=%d max_events=%lld)",
+             H, W, max_refs, max_windows, (long long)max_events_total);
+        return nullptr;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+        fail(nullptr, EINCM_ERR_HIP, "eincm_create: no HIP device visible (%s); this engine has no CPU fallback",
+             hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        fail(nullptr, EINCM_ERR_ARG, "eincm_create: device %d out of range (0..%d)", device, ndev - 1);
+        return nullptr;
+    }
+    eincm_ctx* c = new eincm_ctx();
+    c->device = device; c->H = H; c->W = W; c->maxR = max_refs; c->maxB = max_windows; c->maxN = max_events_total;
+    c->cflags = flags;
+    if (const char* s = getenv("EINCM_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= (1 << 20)) c->chunk = v; }
+    auto bail = [&](const char* what, hipError_t err) -> eincm_ctx* {
+        fail(nullptr, EINCM_ERR_HIP, "eincm_create: %s failed: %s", what, hipGetErrorString(err));
+        free_all(c);
+        delete c;
+        return nullptr;
+    };
+#define TRY(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) return bail(#expr, e2_); } while (0)
+    TRY(hipSetDevice(device));
+    TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const int tilesX = (W + TS - 1) / TS, tilesY = (H + TS - 1) / TS, ntiles = tilesX * tilesY;
+    const size_t B = max_windows, R = max_refs, img = (size_t)H * W;
+    c->max_items = (int64_t)B * ntiles + max_events_total / c->chunk + 1;
+    c->coarse_cap = std::max<int64_t>(64 * 64 * 2, 2);   // coarse theta up to 64x64 (the pyramid tops out at 16x16)
+    TRY(dalloc(&c->d_xy, (size_t)max_events_total));
+    TRY(dalloc(&c->d_t, (size_t)max_events_total));
+    TRY(dalloc(&c->d_items, (size_t)c->max_items));
+    TRY(dalloc(&c->d_edges, B * R * img));
+    TRY(dalloc(&c->d_edge_ts, B * R));
+    TRY(dalloc(&c->d_iwe, B * R * img));
+    TRY(dalloc(&c->d_G, B * R * img));
+    TRY(dalloc(&c->d_zero_iwe, B * img));
+    TRY(dalloc(&c->d_Theta, B * img * 2));
+    TRY(dalloc(&c->d_theta_in, B * img * 2));
+    TRY(dalloc(&c->d_gTheta, B * img * 2));
+    TRY(dalloc(&c->d_tvg, B * img * 2));
+    TRY(dalloc(&c->d_mask, B * img));
+    TRY(dalloc(&c->d_tmm, B * ntiles * 4));
+    TRY(dalloc(&c->d_parts, B * R * ntiles));
+    TRY(dalloc(&c->d_divparts, B * R * ntiles));
+    TRY(dalloc(&c->d_tvparts, B * ntiles * 3));
+    TRY(dalloc(&c->d_wc, B));
+    TRY(dalloc(&c->d_outs, B));
+    TRY(dalloc(&c->d_gth, 2 * B * (size_t)c->coarse_cap));
+    TRY(dalloc(&c->d_grad, B * img * 2));
+    TRY(dalloc(&c->d_rowtap, (size_t)H));
+    TRY(dalloc(&c->d_coltap, (size_t)W));
+    TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_theta), B * img * 2 * sizeof(double), hipHostMallocDefault));
+    TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_grad), B * img * 2 * sizeof(double), hipHostMallocDefault));
+    TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_outs), B * sizeof(OutScal), hipHostMallocDefault));
+    TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_wc), B * sizeof(WinConst), hipHostMallocDefault));
+    for (int i = 0; i <= EINCM_N_STAGES; ++i) { TRY(hipEventCreate(&c->ev[i][0])); TRY(hipEventCreate(&c->ev[i][1])); c->ev_used[i] = false; }
+    c->have_events = true;
+    // both event kernels need > 32 KiB... (<= 64 KiB default limit is fine on gfx950, no attribute needed)
+#undef TRY
+    return c;
+}
+
+void eincm_destroy(eincm_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_all(ctx);
+    delete ctx;
+}
+
+int eincm_set_windows(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* xs, const int16_t* ys,
+                      const double* ts, const double* edges, const double* edge_ts) {
+    if (!c) return EINCM_ERR_ARG;
+    if (n_windows < 1 || n_windows > c->maxB) return fail(c, EINCM_ERR_ARG, "n_windows %d outside 1..%d", n_windows, c->maxB);
+    if (n_refs < 1 || n_refs > c->maxR) return fail(c, EINCM_ERR_ARG, "n_refs %d outside 1..%d", n_refs, c->maxR);
+    if (!n_events || !xs || !ys || !ts || !edges || !edge_ts) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int H = c->H, W = c->W;
+    int64_t N = 0;
+    for (int b = 0; b < n_windows; ++b) {
+        if (n_events[b] < 0) return fail(c, EINCM_ERR_ARG, "n_events[%d] negative", b);
+        N += n_events[b];
+    }
+    if (N > c->maxN) return fail(c, EINCM_ERR_ARG, "total events %lld exceed capacity %lld", (long long)N, (long long)c->maxN);
+    c->staged = false;
+    Geom g{};
+    g.H = H; g.W = W; g.R = n_refs; g.B = n_windows;
+    g.tilesX = (W + TS - 1) / TS; g.tilesY = (H + TS - 1) / TS; g.ntiles = g.tilesX * g.tilesY;
+
+    // ---- bin by (window, source tile), stable in the input (time) order; cut bins into work items ----
+    std::vector<uint32_t> sxy((size_t)std::max<int64_t>(N, 1));
+    std::vector<double> st((size_t)std::max<int64_t>(N, 1));
+    std::vector<Item> items;
+    std::vector<int64_t> cnt((size_t)g.ntiles + 1);
+    int64_t base = 0;
+    for (int b = 0; b < n_windows; ++b) {
+        const int64_t n = n_events[b];
+        const int16_t* x = xs + base; const int16_t* y = ys + base; const double* t = ts + base;
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int64_t i = 0; i < n; ++i) {
+            if (x[i] < 0 || x[i] >= W || y[i] < 0 || y[i] >= H)
+                return fail(c, EINCM_ERR_ARG, "event %lld of window %d at (x=%d, y=%d) outside the %dx%d sensor",
+                            (long long)i, b, (int)x[i], (int)y[i], H, W);
+            if (!std::isfinite(t[i])) return fail(c, EINCM_ERR_ARG, "event %lld of window %d has a non-finite timestamp", (long long)i, b);
+            ++cnt[(size_t)(y[i] / TS) * g.tilesX + (x[i] / TS) + 1];
+        }
+        for (int k = 0; k < g.ntiles; ++k) cnt[k + 1] += cnt[k];
+        std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
+        for (int64_t i = 0; i < n; ++i) {
+            const int tile = (y[i] / TS) * g.tilesX + (x[i] / TS);
+            const int64_t d = base + pos[tile]++;
+            sxy[d] = (uint32_t)(uint16_t)x[i] | ((uint32_t)(uint16_t)y[i] << 16);
+            st[d] = t[i];
+        }
+        for (int k = 0; k < g.ntiles; ++k) {
+            for (int64_t s = cnt[k]; s < cnt[k + 1]; s += c->chunk) {
+                Item it;
+                it.win = b; it.tile = k; it.begin = (int32_t)(base + s);
+                it.count = (int32_t)std::min<int64_t>(c->chunk, cnt[k + 1] - s);
+                double lo = st[it.begin], hi = st[it.begin];
+                for (int q = 1; q < it.count; ++q) { lo = std::min(lo, st[it.begin + q]); hi = std::max(hi, st[it.begin + q]); }
+                it.t_lo = lo; it.t_hi = hi;
+                items.push_back(it);
+            }
+        }
+        base += n;
+    }
+    if ((int64_t)items.size() > c->max_items) return fail(c, EINCM_ERR_ARG, "internal: %zu work items exceed capacity", items.size());
+
+    // ---- edges -> fp32 (+ their moments in fp64 of the stored values), constants, uploads ----
+    const size_t img = (size_t)H * W;
+    std::vector<float> ef((size_t)n_windows * n_refs * img);
+    for (int b = 0; b < n_windows; ++b) {
+        WinConst& wc = c->h_wc[b];
+        memset(&wc, 0, sizeof wc);
+        multi_ref_weights(n_refs, wc.mrw);
+        for (int r = 0; r < n_refs; ++r) {
+            const double* e = edges + ((size_t)b * n_refs + r) * img;
+            float* o = ef.data() + ((size_t)b * n_refs + r) * img;
+            double s = 0.0, ss = 0.0;
+            for (size_t i = 0; i < img; ++i) { const float f = (float)e[i]; o[i] = f; s += (double)f; ss += (double)f * (double)f; }
+            wc.sE[r] = s; wc.sEE[r] = ss;
+            if (!std::isfinite(edge_ts[b * n_refs + r])) return fail(c, EINCM_ERR_ARG, "edge_ts[%d,%d] is not finite", b, r);
+        }
+    }
+    if (N > 0) {
+        HIPCHK(c, hipMemcpyAsync(c->d_xy, sxy.data(), (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_t, st.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    if (!items.empty())
+        HIPCHK(c, hipMemcpyAsync(c->d_items, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_edges, ef.data(), ef.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_edge_ts, edge_ts, (size_t)n_windows * n_refs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_mask, 0, (size_t)n_windows * img, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->g = g; c->n_items = (int)items.size(); c->n_events = N;
+    c->win_events.assign(n_events, n_events + n_windows);
+    if (c->n_items > 0) {
+        hipLaunchKernelGGL(k_mask, dim3(std::min(c->n_items, 2048)), dim3(NT), 0, c->stream, g, c->d_items, c->n_items, c->d_xy, c->d_mask);
+        HIPCHK(c, hipGetLastError());
+    }
+
+    // ---- zero-warp constants: one forward pass at theta = 0 (then IWE_r == IUE for every r) ----
+    // c0, zc[r], d0 are temporarily 1 so the pass is well defined; they are overwritten below.
+    for (int b = 0; b < n_windows; ++b) {
+        WinConst& wc = c->h_wc[b];
+        wc.c0_gradmag = 1.0; wc.c0_var = 1.0; wc.d0 = 1.0;
+        for (int r = 0; r < n_refs; ++r) wc.zc[r] = 1.0;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_wc, c->h_wc, (size_t)n_windows * sizeof(WinConst), hipMemcpyHostToDevice, c->stream));
+    c->staged = true;
+    {
+        std::vector<double> zero((size_t)n_windows * 2, 0.0);
+        std::vector<double> val((size_t)n_windows);
+        eincm_params p{};
+        p.alpha = 1.0; p.beta = 1.0; p.cur_pyr_lvl = 1; p.method = EINCM_METHOD_BILINEAR; p.flags = EINCM_PF_FULL_AUX;
+        const int rc = evaluate(c, zero.data(), 1, 1, &p, val.data(), nullptr, nullptr, true);
+        if (rc != EINCM_OK && rc != EINCM_ERR_NONFINITE) { c->staged = false; return rc; }
+    }
+    for (int b = 0; b < n_windows; ++b) {
+        WinConst& wc = c->h_wc[b];
+        const OutScal& o = c->h_outs[b];
+        wc.c0_gradmag = o.contrast_gm[0];
+        wc.c0_var = o.var[0];
+        wc.d0 = o.div[0];
+        for (int r = 0; r < n_refs; ++r) wc.zc[r] = o.corr[r];     // -MSE(E_r, n0)
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_wc, c->h_wc, (size_t)n_windows * sizeof(WinConst), hipMemcpyHostToDevice, c->stream));
+    // keep the IUE of every window (first reference image of the theta = 0 pass)
+    for (int b = 0; b < n_windows; ++b)
+        HIPCHK(c, hipMemcpyAsync(c->d_zero_iwe + (size_t)b * img, c->d_iwe + (size_t)b * n_refs * img, img * sizeof(float),
+                                 hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_eval = false;
+    c->err.clear();
+    return EINCM_OK;
+}
+
+int eincm_loss_grad(eincm_ctx* c, const double* theta, int h, int w, const eincm_params* p, double* value, double* grad, eincm_aux* aux) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!c->staged) return fail(c, EINCM_ERR_STATE, "eincm_loss_grad called before eincm_set_windows");
+    if (!theta || !p || !value) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (h < 1 || w < 1) return fail(c, EINCM_ERR_ARG, "theta shape (%d,%d,2) invalid", h, w);
+    if (p->method < 0 || p->method > EINCM_METHOD_CUBIC) return fail(c, EINCM_ERR_ARG, "method %d unknown", p->method);
+    HIPCHK(c, hipSetDevice(c->device));
+    return evaluate(c, theta, h, w, p, value, grad, aux, false);
+}
+
+int eincm_handover_loss_grad(eincm_ctx* c, const double* a, const double* prev_theta, const double* theta, int h, int w,
+                             const eincm_params* p, double* value, double* dvalue_da) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!c->staged) return fail(c, EINCM_ERR_STATE, "eincm_handover_loss_grad called before eincm_set_windows");
+    if (!a || !prev_theta || !theta || !p || !value) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (h < 1 || w < 1) return fail(c, EINCM_ERR_ARG, "theta shape (%d,%d,2) invalid", h, w);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nth = (size_t)h * w * 2, B = c->g.B;
+    std::vector<double> tho(B * nth), grad;
+    for (size_t b = 0; b < B; ++b)
+        for (size_t i = 0; i < nth; ++i)   // losses.py:269
+            tho[b * nth + i] = a[b] * prev_theta[b * nth + i] + (1.0 - a[b]) * theta[b * nth + i];
+    if (dvalue_da) grad.resize(B * nth);
+    const int rc = evaluate(c, tho.data(), h, w, p, value, dvalue_da ? grad.data() : nullptr, nullptr, false);
+    if (rc != EINCM_OK && rc != EINCM_ERR_NONFINITE) return rc;
+    if (dvalue_da) {
+        for (size_t b = 0; b < B; ++b) {
+            double s = 0.0;
+            for (size_t i = 0; i < nth; ++i) s += grad[b * nth + i] * (prev_theta[b * nth + i] - theta[b * nth + i]);
+            dvalue_da[b] = s;
+        }
+    }
+    return rc;
+}
+
+int eincm_objectives(eincm_ctx* c, const double* Theta, eincm_objectives_out* out) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!c->staged) return fail(c, EINCM_ERR_STATE, "eincm_objectives called before eincm_set_windows");
+    if (!Theta || !out) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const Geom& g = c->g;
+    eincm_params p{};
+    p.alpha = 1.0; p.beta = 1.0; p.gamma = 0.0; p.delta = 0.0; p.cur_pyr_lvl = 0; p.method = EINCM_METHOD_BILINEAR;
+    p.flags = EINCM_PF_FULL_AUX;
+    std::vector<double> val((size_t)g.B);
+    const int rc = evaluate(c, Theta, g.H, g.W, &p, val.data(), nullptr, nullptr, false);
+    if (rc != EINCM_OK && rc != EINCM_ERR_NONFINITE) return rc;
+    std::vector<double> tvp((size_t)g.B * g.ntiles * 3);
+    HIPCHK(c, hipMemcpy(tvp.data(), c->d_tvparts, tvp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const double HW = (double)g.H * g.W;
+    for (int b = 0; b < g.B; ++b) {
+        eincm_objectives_out& o = out[b];
+        memset(&o, 0, sizeof o);
+        const OutScal& s = c->h_outs[b];
+        const WinConst& wc = c->h_wc[b];
+        o.n_refs = g.R;
+        o.zero_contrast = wc.c0_gradmag; o.zero_variance = wc.c0_var; o.zero_iwe_divergence = wc.d0;
+        for (int r = 0; r < g.R; ++r) {
+            o.correlations[r] = s.corr[r];
+            o.zero_correlations[r] = wc.zc[r];
+            o.rel_correlations[r] = s.corr[r] / (wc.zc[r] + EPSN);
+            o.contrasts[r] = s.contrast_gm[r];
+            o.rel_contrasts[r] = s.contrast_gm[r] / (wc.c0_gradmag + EPSN);
+            o.iwe_divergences[r] = s.div[r];
+            o.rel_iwe_divergences[r] = s.div[r] / (wc.d0 + EPSN);
+            o.variances[r] = s.var[r];
+            o.flow_warp_losses[r] = s.var[r] / wc.c0_var;          // contrast_metrics.py:17
+            o.multi_ref_weights[r] = wc.mrw[r];
+        }
+        o.theta_total_variation = s.tv;
+        double td = 0.0;
+        for (int k = 0; k < g.ntiles; ++k) td += tvp[((size_t)b * g.ntiles + k) * 3 + 2];
+        o.theta_divergence = td / HW;
+    }
+    return rc;
+}
+
+static int copy_out(eincm_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!dst) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (!c->staged) return fail(c, EINCM_ERR_STATE, "no staged windows");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return EINCM_OK;
+}
+
+int eincm_get_iwes(eincm_ctx* c, float* iwes) {
+    if (c && !c->have_eval) return fail(c, EINCM_ERR_STATE, "no evaluation yet");
+    return copy_out(c, iwes, c ? c->d_iwe : nullptr, c ? (size_t)c->g.B * c->g.R * c->g.H * c->g.W * sizeof(float) : 0);
+}
+int eincm_get_zero_iwe(eincm_ctx* c, float* z) {
+    return copy_out(c, z, c ? c->d_zero_iwe : nullptr, c ? (size_t)c->g.B * c->g.H * c->g.W * sizeof(float) : 0);
+}
+int eincm_get_image_grad(eincm_ctx* c, float* G) {
+    if (c && !c->have_eval) return fail(c, EINCM_ERR_STATE, "no evaluation yet");
+    return copy_out(c, G, c ? c->d_G : nullptr, c ? (size_t)c->g.B * c->g.R * c->g.H * c->g.W * sizeof(float) : 0);
+}
+int eincm_get_scaled_theta(eincm_ctx* c, double* T) {
+    if (c && !c->have_eval) return fail(c, EINCM_ERR_STATE, "no evaluation yet");
+    return copy_out(c, T, c ? c->d_Theta : nullptr, c ? (size_t)c->g.B * c->g.H * c->g.W * 2 * sizeof(double) : 0);
+}
+
+int eincm_get_timings(eincm_ctx* c, eincm_timings* t) {
+    if (!c || !t) return EINCM_ERR_ARG;
+    if (!(c->cflags & EINCM_CF_TIMING)) return fail(c, EINCM_ERR_STATE, "context was created without EINCM_CF_TIMING");
+    *t = c->last_t;
+    return EINCM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,961 @@
+// eincm_kernels.hip.h — gfx950 device code of the EINCM objective-and-gradient engine.
+//
+// One evaluation of loss(theta) -> (value, grad) is the launch sequence
+//   k_theta   theta (h,w,2) -> Theta (H,W,2) fp64 + per-tile velocity bounds      [theta_utils.py:25-35]
+//   k_splat   warp + 3x3 Gaussian splat of every event at every reference time     [event_warpers.py:28-35,
+//             into an LDS-resident destination window, flushed row-wise to HBM      event_utils.py:31-59]
+//   k_stats   per-image min/max(+tie counts)/moments/Scharr energy partials        [img_utils.py:24-25,414-421;
+//                                                                                    contrast_objectives.py:22-25]
+//   k_imgrad  dL/dIWE image (contrast adjoint stencil + MSE-through-normalise)      [reverse of losses.py:61-72]
+//   k_gather  backward of the splat: 9-tap gather of dL/dIWE per event -> dL/dTheta [reverse of event_utils.py:59]
+//   k_tv      masked-flow total variation + its (unscaled) gradient image           [regularizers.py:14-38]
+//   k_project adjoint resample dL/dTheta -> dL/dtheta                               [reverse of theta_utils.py:25-35]
+//   k_final   scalar assembly of the loss, aux and the final gradient               [losses.py:176-203]
+// Events are binned once per window by 32x32 SOURCE tile (time order kept inside a tile) and cut into
+// work items of <= chunk events; because Theta is smooth and an item spans a known time range, the
+// destinations of an item fall in a small bounding box that lives in LDS (fp32 ds_add), so HBM sees one
+// coalesced row-wise flush per item instead of 9 scattered atomics per warped event.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace eincm {
+
+constexpr int TS = 32;            // source tile edge (pixels)
+constexpr int NT = 256;           // threads per workgroup = 4 waves of 64
+constexpr int NWAVE = NT / 64;
+constexpr int WIN_CAP = 9216;     // floats of LDS for an item's destination window (36 KiB)
+constexpr int WIN_MAXW = 96;
+constexpr double EPSN = 2.220446049250313e-16;   // sys.float_info.epsilon (losses.py:24)
+constexpr float INV_2PI = 0.15915494309189535f;
+constexpr float EXP_M05 = 0.6065306597126334f;   // exp(-1/2)
+
+struct Geom {
+    int H, W, R, B;
+    int tilesX, tilesY, ntiles;
+};
+
+struct Item {                     // one unit of event work: <= chunk events of one source tile of one window
+    int32_t win, tile, begin, count;
+    double t_lo, t_hi;            // time range of its events
+};
+
+struct StatPart {                 // per (window, ref, tile) partial of the image reductions
+    double mn, mx, cmn, cmx;      // min, max and how many pixels attain them inside the tile
+    double sI, sII, sEI, sG2;     // sum I, sum I^2, sum E*I, sum (gx^2+gy^2)
+};
+
+struct ImgScal {                  // per (window, ref) reduced scalars
+    double m, M, D, cm, cM, sI, sII, sEI, sG2;
+};
+
+struct WinConst {                 // theta-independent constants of a window (losses.py:54-55,66,71,80,84)
+    double c0_gradmag, c0_var, d0;
+    double zc[16];                // zero_corrs[r] = -MSE(E_r, n0)
+    double sE[16], sEE[16];       // sum E_r, sum E_r^2
+    double mrw[16];               // multi-reference weights (losses.py:39-46)
+};
+
+struct EvalParams {
+    double alpha, beta, gamma, delta;
+    int cur_pyr_lvl, contrast_kind;
+    int want_div, want_tv, use_tv_grad;
+    int h, w, identity;
+};
+
+struct OutScal {                  // per-window result block written by k_final
+    double value, mean_rel_corr, mean_rel_contrast, mean_rel_div, tv, tv_scale, nonfinite, _pad;
+    double corr[16], contrast_gm[16], var[16], div[16];
+};
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+// JAX scatter/gather index rule for frame.at[rs, cs].add(mode='drop') (event_utils.py:59): negative indices
+// are normalised first (p in [-n,-1] -> p+n), anything still outside [0,n) is dropped.  Returns -1 for a drop.
+__device__ __forceinline__ int wrap_drop(int p, int n) {
+    p += (p < 0) ? n : 0;
+    return (p >= 0 && p < n) ? p : -1;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// block-wide sum of a double; result valid in thread 0.  scratch: >= NWAVE doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wv] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NWAVE; ++i) r += scratch[i];
+    }
+    return r;
+}
+
+struct Window { int ox, oy, ww, wh; };
+
+// Destination bounding box of an item at reference time tau: source tile shifted by -v*dt for
+// v in the tile's velocity bounds and dt in the item's time range, +1 for the 3x3 taps, +1 for rounding.
+// Clamped to WIN_CAP floats; taps that fall outside take the (rare) direct-to-HBM path, so ANY box is correct.
+__device__ __forceinline__ Window item_window(const Geom& g, const Item& it, const double* __restrict__ mm4, double tau) {
+    const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
+    const int x0 = tx * TS, y0 = ty * TS;
+    const int x1 = min(x0 + TS, g.W) - 1, y1 = min(y0 + TS, g.H) - 1;
+    const double dlo = it.t_lo - tau, dhi = it.t_hi - tau;
+    const double LIM = 4096.0;
+    double lo[2], hi[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const double vmin = mm4[2 * c], vmax = mm4[2 * c + 1];
+        const double a = -vmin * dlo, b = -vmin * dhi, cc = -vmax * dlo, d = -vmax * dhi;
+        double mn = fmin(fmin(a, b), fmin(cc, d)), mx = fmax(fmax(a, b), fmax(cc, d));
+        if (!(mn == mn) || !(mx == mx)) { mn = 0.0; mx = 0.0; }          // NaN theta: any window is correct
+        lo[c] = floor(fmin(fmax(mn, -LIM), LIM));
+        hi[c] = ceil(fmin(fmax(mx, -LIM), LIM));
+    }
+    int bx0 = x0 + (int)lo[0] - 2, bx1 = x1 + (int)hi[0] + 2;
+    int by0 = y0 + (int)lo[1] - 2, by1 = y1 + (int)hi[1] + 2;
+    int ww = bx1 - bx0 + 1, wh = by1 - by0 + 1;
+    if (ww * wh > WIN_CAP || ww > WIN_MAXW) {
+        const int nww = min(ww, WIN_MAXW);
+        const int nwh = min(wh, WIN_CAP / nww);
+        bx0 = (bx0 + bx1) / 2 - nww / 2;
+        by0 = (by0 + by1) / 2 - nwh / 2;
+        ww = nww; wh = nwh;
+    }
+    Window w; w.ox = bx0; w.oy = by0; w.ww = ww; w.wh = wh;
+    return w;
+}
+
+// Warp one coordinate (event_warpers.py:34-35) and split it the way events_to_pdf_frame does
+// (event_utils.py:32-33): w = x - v*dt (fp64, same operations as the reference so the half-to-even rounding
+// decisions agree), r = rint(w), f = w - r in [-0.5, 0.5] (exact in fp64), returned as (int r, float f).
+__device__ __forceinline__ void warp_axis(int x, double v, double dt, int& ir, float& f) {
+    const double w = (double)x - v * dt;
+    const double r = rint(w);
+    const double fr = w - r;
+    const bool ok = fabs(w) < 1.0e6;                 // |w| beyond any sensor: every tap is dropped
+    ir = ok ? (int)r : -(1 << 24);
+    f = ok ? (float)fr : 0.0f;
+}
+
+// Separable 3-tap weights exp(-0.5*(d - f)^2), d = -1,0,1 (event_utils.py:52-56; the 1/(2*pi) is folded by the caller)
+__device__ __forceinline__ void taps3(float f, float& wm, float& w0, float& wp) {
+    const float e0 = __expf(-0.5f * f * f);
+    const float ep = __expf(f);
+    const float em = __frcp_rn(ep);
+    wm = e0 * em * EXP_M05;     // d = -1: exp(-0.5 f^2 - f - 0.5)
+    w0 = e0;
+    wp = e0 * ep * EXP_M05;     // d = +1
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_theta: Theta = A_H theta A_W^T per channel, and per-tile velocity bounds.
+// grid (ntiles, B).  identity: theta already is (H,W,2).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity,
+        const double* __restrict__ theta,      // (B,h,w,2)
+        const double* __restrict__ AH,         // (H,h)
+        const double* __restrict__ AW,         // (W,w)
+        const int2* __restrict__ rowtap,       // (H) [lo,hi) non-zero range of AH[y,:]
+        const int2* __restrict__ coltap,       // (W)
+        double* __restrict__ Theta,            // (B,H,W,2)
+        double* __restrict__ tmm)              // (B,ntiles,4) vxmin,vxmax,vymin,vymax
+{
+    __shared__ double red[4][NWAVE];
+    __shared__ double nanred[NWAVE];
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int tx = tile % g.tilesX, ty = tile / g.tilesX;
+    const double* th = theta + (size_t)b * h * w * 2;
+    double* Th = Theta + (size_t)b * g.H * g.W * 2;
+    double mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+    bool nan = false;
+    for (int p = threadIdx.x; p < TS * TS; p += NT) {
+        const int y = ty * TS + p / TS, x = tx * TS + p % TS;
+        if (y >= g.H || x >= g.W) continue;
+        double vx, vy;
+        if (identity) {
+            const double2 v = *reinterpret_cast<const double2*>(th + ((size_t)y * g.W + x) * 2);
+            vx = v.x; vy = v.y;
+        } else {
+            const int2 rt = rowtap[y], ct = coltap[x];
+            vx = 0.0; vy = 0.0;
+            for (int i = rt.x; i < rt.y; ++i) {
+                const double a = AH[(size_t)y * h + i];
+                double sx = 0.0, sy = 0.0;
+                for (int j = ct.x; j < ct.y; ++j) {
+                    const double bw = AW[(size_t)x * w + j];
+                    const double2 v = *reinterpret_cast<const double2*>(th + ((size_t)i * w + j) * 2);
+                    sx += bw * v.x; sy += bw * v.y;
+                }
+                vx += a * sx; vy += a * sy;
+            }
+        }
+        *reinterpret_cast<double2*>(Th + ((size_t)y * g.W + x) * 2) = make_double2(vx, vy);
+        nan |= !(vx == vx) || !(vy == vy);
+        mnx = fmin(mnx, vx); mxx = fmax(mxx, vx); mny = fmin(mny, vy); mxy = fmax(mxy, vy);
+    }
+    if (nan) { mnx = mxx = mny = mxy = NAN; }   // fmin/fmax drop NaNs; keep them visible to item_window
+    mnx = wave_min(mnx); mxx = wave_max(mxx); mny = wave_min(mny); mxy = wave_max(mxy);
+    // NaN-ness must survive the reduction: reduce a flag alongside
+    const double nanf = wave_max(nan ? 1.0 : 0.0);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wv] = mnx; red[1][wv] = mxx; red[2][wv] = mny; red[3][wv] = mxy; nanred[wv] = nanf; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = red[0][0], bq = red[1][0], c = red[2][0], d = red[3][0], nf = nanred[0];
+        for (int i = 1; i < NWAVE; ++i) {
+            a = fmin(a, red[0][i]); bq = fmax(bq, red[1][i]); c = fmin(c, red[2][i]); d = fmax(d, red[3][i]);
+            nf = fmax(nf, nanred[i]);
+        }
+        double* o = tmm + ((size_t)b * g.ntiles + tile) * 4;
+        if (nf > 0.0) { a = bq = c = d = NAN; }
+        o[0] = a; o[1] = bq; o[2] = c; o[3] = d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_splat: the dominant kernel.  grid (n_items, R).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_splat(Geom g,
+        const Item* __restrict__ items,
+        const uint32_t* __restrict__ ev_xy,    // x | y << 16, binned by (window, tile)
+        const double* __restrict__ ev_t,
+        const double* __restrict__ Theta,      // (B,H,W,2)
+        const double* __restrict__ tmm,        // (B,ntiles,4)
+        const double* __restrict__ edge_ts,    // (B,R)
+        float* __restrict__ iwe)               // (B,R,H,W), zeroed
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Item it = items[blockIdx.x];
+    const int r = blockIdx.y;
+    const double tau = edge_ts[it.win * g.R + r];
+    const Window wn = item_window(g, it, tmm + ((size_t)it.win * g.ntiles + it.tile) * 4, tau);
+    const int nwin = wn.ww * wn.wh;
+    for (int i = threadIdx.x; i < nwin; i += NT) lds[i] = 0.0f;
+    __syncthreads();
+
+    float* __restrict__ img = iwe + ((size_t)it.win * g.R + r) * g.H * g.W;
+    const double* __restrict__ Th = Theta + (size_t)it.win * g.H * g.W * 2;
+    const uint32_t* __restrict__ exy = ev_xy + it.begin;
+    const double* __restrict__ et = ev_t + it.begin;
+
+    for (int i = threadIdx.x; i < it.count; i += NT) {
+        const uint32_t xy = exy[i];
+        const double dt = et[i] - tau;
+        const int x = xy & 0xffff, y = xy >> 16;
+        const double2 v = *reinterpret_cast<const double2*>(Th + ((size_t)y * g.W + x) * 2);
+        int irx, iry; float fx, fy;
+        warp_axis(x, v.x, dt, irx, fx);
+        warp_axis(y, v.y, dt, iry, fy);
+        float kx[3], ky[3];
+        taps3(fx, kx[0], kx[1], kx[2]);
+        taps3(fy, ky[0], ky[1], ky[2]);
+        ky[0] *= INV_2PI; ky[1] *= INV_2PI; ky[2] *= INV_2PI;
+        const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;        // window coords of the top-left tap
+        if (lx >= 0 && ly >= 0 && lx + 2 < wn.ww && ly + 2 < wn.wh) {
+            float* p = lds + ly * wn.ww + lx;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) atomicAdd(p + dy * wn.ww + dx, ky[dy] * kx[dx]);
+            }
+        } else {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int cx = lx + dx, cy = ly + dy;
+                    const float k = ky[dy] * kx[dx];
+                    if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
+                        atomicAdd(lds + cy * wn.ww + cx, k);
+                    } else {
+                        const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
+                        if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, k);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // row-wise flush: a wave walks one window row -> contiguous fp32 atomics on one image row
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int row = wv; row < wn.wh; row += NWAVE) {
+        const int gy = wrap_drop(wn.oy + row, g.H);
+        if (gy < 0) continue;
+        for (int col = lane; col < wn.ww; col += 64) {
+            const float v = lds[row * wn.ww + col];
+            if (v != 0.0f) {
+                const int gx = wrap_drop(wn.ox + col, g.W);
+                if (gx >= 0) atomicAdd(img + (size_t)gy * g.W + gx, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scharr 'same' true convolution, zero padded, difference-first (see oracle scharr_grads for why):
+//   gx = 3(p[y+1,x+1]-p[y+1,x-1]) + 10(p[y,x+1]-p[y,x-1]) + 3(p[y-1,x+1]-p[y-1,x-1])
+//   gy = 3(p[y+1,x+1]-p[y-1,x+1]) + 10(p[y+1,x]-p[y-1,x]) + 3(p[y+1,x-1]-p[y-1,x-1])
+// T is an LDS tile accessor a(y, x) returning double.
+// ------------------------------------------------------------------------------------------------
+template <typename A> __device__ __forceinline__ void scharr_at(const A& a, int y, int x, double& gx, double& gy) {
+    const double ul = a(y - 1, x - 1), uc = a(y - 1, x), ur = a(y - 1, x + 1);
+    const double ml = a(y, x - 1), mr = a(y, x + 1);
+    const double dl = a(y + 1, x - 1), dc = a(y + 1, x), dr = a(y + 1, x + 1);
+    gx = 3.0 * (dr - dl) + 10.0 * (mr - ml) + 3.0 * (ur - ul);
+    gy = 3.0 * (dr - ur) + 10.0 * (dc - uc) + 3.0 * (dl - ul);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_stats: grid (ntiles, R, B).  img_of_r: stride between reference images (0 when one image serves all refs).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_stats(Geom g, const float* __restrict__ iwe, const float* __restrict__ edges,
+                                               StatPart* __restrict__ parts)
+{
+    constexpr int P = TS + 2, PP = P + 1;
+    __shared__ float t[P][PP];
+    __shared__ double red[NWAVE][8];
+    const int tile = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
+    const int tx = tile % g.tilesX, ty = tile / g.tilesX;
+    const int x0 = tx * TS, y0 = ty * TS;
+    const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
+    const float* __restrict__ E = edges + ((size_t)b * g.R + r) * g.H * g.W;
+    for (int p = threadIdx.x; p < P * P; p += NT) {
+        const int ly = p / P, lx = p % P;
+        const int y = y0 + ly - 1, x = x0 + lx - 1;
+        t[ly][lx] = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? I[(size_t)y * g.W + x] : 0.0f;
+    }
+    __syncthreads();
+    auto acc = [&](int y, int x) -> double { return (double)t[y][x]; };
+    double mn = INFINITY, mx = -INFINITY, cmn = 0.0, cmx = 0.0, sI = 0.0, sII = 0.0, sEI = 0.0, sG2 = 0.0;
+    for (int p = threadIdx.x; p < TS * TS; p += NT) {
+        const int ly = p / TS, lx = p % TS;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= g.H || x >= g.W) continue;
+        const double v = acc(ly + 1, lx + 1);
+        const double e = (double)E[(size_t)y * g.W + x];
+        if (v < mn) { mn = v; cmn = 1.0; } else if (v == mn) cmn += 1.0;
+        if (v > mx) { mx = v; cmx = 1.0; } else if (v == mx) cmx += 1.0;
+        sI += v; sII += v * v; sEI += e * v;
+        double gx, gy;
+        scharr_at(acc, ly + 1, lx + 1, gx, gy);
+        sG2 += gx * gx + gy * gy;
+    }
+    // (min,count) / (max,count) pairs combine associatively
+    const double wmn = wave_min(mn), wmx = wave_max(mx);
+    const double bmn = __shfl(wmn, 0, 64), bmx = __shfl(wmx, 0, 64);
+    cmn = wave_sum(mn == bmn ? cmn : 0.0);
+    cmx = wave_sum(mx == bmx ? cmx : 0.0);
+    sI = wave_sum(sI); sII = wave_sum(sII); sEI = wave_sum(sEI); sG2 = wave_sum(sG2);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[wv][0] = bmn; red[wv][1] = bmx; red[wv][2] = cmn; red[wv][3] = cmx;
+        red[wv][4] = sI; red[wv][5] = sII; red[wv][6] = sEI; red[wv][7] = sG2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        StatPart o;
+        o.mn = red[0][0]; o.mx = red[0][1]; o.cmn = red[0][2]; o.cmx = red[0][3];
+        o.sI = red[0][4]; o.sII = red[0][5]; o.sEI = red[0][6]; o.sG2 = red[0][7];
+        for (int i = 1; i < NWAVE; ++i) {
+            if (red[i][0] < o.mn) { o.mn = red[i][0]; o.cmn = red[i][2]; } else if (red[i][0] == o.mn) o.cmn += red[i][2];
+            if (red[i][1] > o.mx) { o.mx = red[i][1]; o.cmx = red[i][3]; } else if (red[i][1] == o.mx) o.cmx += red[i][3];
+            o.sI += red[i][4]; o.sII += red[i][5]; o.sEI += red[i][6]; o.sG2 += red[i][7];
+        }
+        parts[((size_t)b * g.R + r) * g.ntiles + tile] = o;
+    }
+}
+
+// Reduce the ntiles StatParts of image (b, r).  Must be called by a full wave (64 lanes); result in all lanes.
+__device__ __forceinline__ ImgScal reduce_parts(const StatPart* __restrict__ parts, int ntiles) {
+    const int lane = threadIdx.x & 63;
+    double mn = INFINITY, mx = -INFINITY, cmn = 0.0, cmx = 0.0, sI = 0.0, sII = 0.0, sEI = 0.0, sG2 = 0.0;
+    for (int i = lane; i < ntiles; i += 64) {
+        const StatPart p = parts[i];
+        if (p.mn < mn) { mn = p.mn; cmn = p.cmn; } else if (p.mn == mn) cmn += p.cmn;
+        if (p.mx > mx) { mx = p.mx; cmx = p.cmx; } else if (p.mx == mx) cmx += p.cmx;
+        sI += p.sI; sII += p.sII; sEI += p.sEI; sG2 += p.sG2;
+    }
+    ImgScal s;
+    double wmn = wave_min(mn), wmx = wave_max(mx);
+    s.m = __shfl(wmn, 0, 64); s.M = __shfl(wmx, 0, 64);
+    s.cm = __shfl(wave_sum(mn == s.m ? cmn : 0.0), 0, 64);
+    s.cM = __shfl(wave_sum(mx == s.M ? cmx : 0.0), 0, 64);
+    s.sI = __shfl(wave_sum(sI), 0, 64); s.sII = __shfl(wave_sum(sII), 0, 64);
+    s.sEI = __shfl(wave_sum(sEI), 0, 64); s.sG2 = __shfl(wave_sum(sG2), 0, 64);
+    s.D = s.M - s.m + EPSN;                                  // img_utils.py:25
+    return s;
+}
+
+// mean((E - n)^2) with n = (I - m)/D from the moments (correlation_objectives.py:25-26 on img_utils.py:24-25)
+__device__ __forceinline__ double mse_from_moments(const ImgScal& s, double sE, double sEE, double HW) {
+    const double a = s.m / s.D;
+    return (sEE + HW * a * a + s.sII / (s.D * s.D) + 2.0 * a * sE - 2.0 * s.sEI / s.D - 2.0 * a * s.sI / s.D) / HW;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_imgrad: G = dL/dIWE.  grid (ntiles, R, B).
+//   contrast (grad-mag): a_r * (2/HW) * (adj_Sx(gx) + adj_Sy(gy)),  adj_S(c) = -conv_same(c, S) for Scharr
+//   contrast (variance): a_r * (2/HW) * (I - mean I)
+//   correlation:         Gn/D + dm*[I==m]/#min + dM*[I==M]/#max,  Gn = b_r*(2/HW)*(E - n)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
+        const float* __restrict__ iwe, const float* __restrict__ edges,
+        const StatPart* __restrict__ parts, const WinConst* __restrict__ wc,
+        float* __restrict__ G)
+{
+    constexpr int P2 = TS + 4, P1 = TS + 2;
+    __shared__ float t[P2][P2 + 1];
+    __shared__ double sgx[P1][P1 + 1], sgy[P1][P1 + 1];
+    __shared__ double sc[8];
+    const int tile = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
+    const int tx = tile % g.tilesX, ty = tile / g.tilesX;
+    const int x0 = tx * TS, y0 = ty * TS;
+    const double HW = (double)g.H * (double)g.W;
+    const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
+    const float* __restrict__ E = edges + ((size_t)b * g.R + r) * g.H * g.W;
+    float* __restrict__ Go = G + ((size_t)b * g.R + r) * g.H * g.W;
+    const WinConst& c = wc[b];
+
+    if (threadIdx.x < 64) {
+        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.ntiles);
+        if (threadIdx.x == 0) {
+            const double c0 = (ep.contrast_kind == 1) ? c.c0_var : c.c0_gradmag;
+            const double a_r = -ep.alpha * c.mrw[r] / ((double)g.R * (c0 + EPSN));
+            const double b_r = -ep.beta * c.mrw[r] / ((double)g.R * (c.zc[r] + EPSN));
+            const double a = s.m / s.D;
+            const double S_n = s.sI / s.D - HW * a;
+            const double S_En = s.sEI / s.D - a * c.sE[r];
+            const double S_nn = s.sII / (s.D * s.D) - 2.0 * a * s.sI / s.D + HW * a * a;
+            const double k = b_r * 2.0 / HW;
+            const double sGn_n = k * (S_En - S_nn);          // sum Gn*n
+            const double sGn = k * (c.sE[r] - S_n);          // sum Gn
+            sc[0] = s.m; sc[1] = s.M; sc[2] = s.D;
+            sc[3] = a_r * 2.0 / HW;                          // contrast scale
+            sc[4] = k / s.D;                                 // Gn/D scale on (E - n)
+            sc[5] = ((sGn_n - sGn) / s.D) / s.cm;            // dm / #argmin
+            sc[6] = (-sGn_n / s.D) / s.cM;                   // dM / #argmax
+            sc[7] = s.sI / HW;                               // mean I
+        }
+    }
+    for (int p = threadIdx.x; p < P2 * P2; p += NT) {
+        const int ly = p / P2, lx = p % P2;
+        const int y = y0 + ly - 2, x = x0 + lx - 2;
+        t[ly][lx] = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? I[(size_t)y * g.W + x] : 0.0f;
+    }
+    __syncthreads();
+    if (ep.contrast_kind == 0) {
+        auto acc = [&](int y, int x) -> double { return (double)t[y][x]; };
+        for (int p = threadIdx.x; p < P1 * P1; p += NT) {
+            const int ly = p / P1, lx = p % P1;
+            const int y = y0 + ly - 1, x = x0 + lx - 1;
+            double gx = 0.0, gy = 0.0;
+            if (y >= 0 && y < g.H && x >= 0 && x < g.W) scharr_at(acc, ly + 1, lx + 1, gx, gy);   // zero outside the image
+            sgx[ly][lx] = gx; sgy[ly][lx] = gy;
+        }
+        __syncthreads();
+    }
+    const double m = sc[0], M = sc[1], D = sc[2];
+    for (int p = threadIdx.x; p < TS * TS; p += NT) {
+        const int ly = p / TS, lx = p % TS;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= g.H || x >= g.W) continue;
+        const double v = (double)t[ly + 2][lx + 2];
+        double dc;
+        if (ep.contrast_kind == 0) {
+            // adj_Sx(gx) = -conv(gx, Sx), adj_Sy(gy) = -conv(gy, Sy)
+            const int cy = ly + 1, cx = lx + 1;
+            const double ax = 3.0 * (sgx[cy + 1][cx + 1] - sgx[cy + 1][cx - 1]) + 10.0 * (sgx[cy][cx + 1] - sgx[cy][cx - 1])
+                            + 3.0 * (sgx[cy - 1][cx + 1] - sgx[cy - 1][cx - 1]);
+            const double ay = 3.0 * (sgy[cy + 1][cx + 1] - sgy[cy - 1][cx + 1]) + 10.0 * (sgy[cy + 1][cx] - sgy[cy - 1][cx])
+                            + 3.0 * (sgy[cy + 1][cx - 1] - sgy[cy - 1][cx - 1]);
+            dc = -(ax + ay);
+        } else {
+            dc = v - sc[7];
+        }
+        const double n = (v - m) / D;
+        const double e = (double)E[(size_t)y * g.W + x];
+        double gv = sc[3] * dc + sc[4] * (e - n);
+        if (v == m) gv += sc[5];
+        if (v == M) gv += sc[6];
+        Go[(size_t)y * g.W + x] = (float)gv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_div: IWE divergence of the normalised IWE (event_collapse_objectives.py:8-20), forward only.
+//   d = mean | K (*) (n (*) Sx) + K (*) (n (*) Sy) | = mean | K (*) (gx_n + gy_n) |, every stage zero padded.
+// grid (ntiles, R, B); writes one partial sum per tile.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_div(Geom g, const float* __restrict__ iwe, const StatPart* __restrict__ parts,
+                                             double* __restrict__ divparts)
+{
+    constexpr int P2 = TS + 4, P1 = TS + 2;
+    __shared__ double t[P2][P2 + 1];
+    __shared__ double s1[P1][P1 + 1];
+    __shared__ double sc[2];
+    __shared__ double scratch[NWAVE];
+    const int tile = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
+    const int tx = tile % g.tilesX, ty = tile / g.tilesX;
+    const int x0 = tx * TS, y0 = ty * TS;
+    const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
+    if (threadIdx.x < 64) {
+        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.ntiles);
+        if (threadIdx.x == 0) { sc[0] = s.m; sc[1] = s.D; }
+    }
+    __syncthreads();
+    const double m = sc[0], D = sc[1];
+    for (int p = threadIdx.x; p < P2 * P2; p += NT) {
+        const int ly = p / P2, lx = p % P2;
+        const int y = y0 + ly - 2, x = x0 + lx - 2;
+        t[ly][lx] = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? ((double)I[(size_t)y * g.W + x] - m) / D : 0.0;
+    }
+    __syncthreads();
+    auto acc = [&](int y, int x) -> double { return t[y][x]; };
+    for (int p = threadIdx.x; p < P1 * P1; p += NT) {
+        const int ly = p / P1, lx = p % P1;
+        const int y = y0 + ly - 1, x = x0 + lx - 1;
+        double gx = 0.0, gy = 0.0;
+        if (y >= 0 && y < g.H && x >= 0 && x < g.W) scharr_at(acc, ly + 1, lx + 1, gx, gy);
+        s1[ly][lx] = gx + gy;
+    }
+    __syncthreads();
+    double sum = 0.0;
+    for (int p = threadIdx.x; p < TS * TS; p += NT) {
+        const int ly = p / TS, lx = p % TS;
+        if (y0 + ly >= g.H || x0 + lx >= g.W) continue;
+        const int cy = ly + 1, cx = lx + 1;
+        // K is symmetric: convolution == correlation
+        const double d = (1.0 / 12.0) * (s1[cy - 1][cx - 1] + s1[cy - 1][cx + 1] + s1[cy + 1][cx - 1] + s1[cy + 1][cx + 1])
+                       + (1.0 / 6.0) * (s1[cy - 1][cx] + s1[cy + 1][cx] + s1[cy][cx - 1] + s1[cy][cx + 1]);
+        sum += fabs(d);
+    }
+    sum = block_sum(sum, scratch);
+    if (threadIdx.x == 0) divparts[((size_t)b * g.R + r) * g.ntiles + tile] = sum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gather: reverse of the splat.  grid (n_items, R).  For every event of the item and this reference time:
+//   dL/dwx = sum_taps G[p] * k * qx,  dL/dwy likewise (q = p - w; dropped taps contribute 0, wrapped taps read
+//   the wrapped pixel), then dL/dTheta[y,x,:] += -dt * (dL/dwx, dL/dwy)   (event_warpers.py:34-35).
+// The G window is staged in LDS with the same bounding box as the forward; per-pixel sums are accumulated in an
+// LDS copy of the source tile and flushed row-wise.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_gather(Geom g,
+        const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
+        const double* __restrict__ Theta, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
+        const float* __restrict__ G,           // (B,R,H,W)
+        float* __restrict__ gTheta)            // (B,H,W,2), zeroed
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* accum = lds + WIN_CAP;              // TS*TS*2 floats
+    const Item it = items[blockIdx.x];
+    const int r = blockIdx.y;
+    const double tau = edge_ts[it.win * g.R + r];
+    const Window wn = item_window(g, it, tmm + ((size_t)it.win * g.ntiles + it.tile) * 4, tau);
+    const float* __restrict__ Gi = G + ((size_t)it.win * g.R + r) * g.H * g.W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int row = wv; row < wn.wh; row += NWAVE) {
+        const int gy = wrap_drop(wn.oy + row, g.H);
+        for (int col = lane; col < wn.ww; col += 64) {
+            const int gx = wrap_drop(wn.ox + col, g.W);
+            lds[row * wn.ww + col] = (gx >= 0 && gy >= 0) ? Gi[(size_t)gy * g.W + gx] : 0.0f;
+        }
+    }
+    for (int i = threadIdx.x; i < TS * TS * 2; i += NT) accum[i] = 0.0f;
+    __syncthreads();
+
+    const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
+    const int x0 = tx * TS, y0 = ty * TS;
+    const double* __restrict__ Th = Theta + (size_t)it.win * g.H * g.W * 2;
+    const uint32_t* __restrict__ exy = ev_xy + it.begin;
+    const double* __restrict__ et = ev_t + it.begin;
+    for (int i = threadIdx.x; i < it.count; i += NT) {
+        const uint32_t xy = exy[i];
+        const double dt = et[i] - tau;
+        const int x = xy & 0xffff, y = xy >> 16;
+        const double2 v = *reinterpret_cast<const double2*>(Th + ((size_t)y * g.W + x) * 2);
+        int irx, iry; float fx, fy;
+        warp_axis(x, v.x, dt, irx, fx);
+        warp_axis(y, v.y, dt, iry, fy);
+        float kx[3], ky[3];
+        taps3(fx, kx[0], kx[1], kx[2]);
+        taps3(fy, ky[0], ky[1], ky[2]);
+        ky[0] *= INV_2PI; ky[1] *= INV_2PI; ky[2] *= INV_2PI;
+        float gv[3][3];
+        const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;
+        if (lx >= 0 && ly >= 0 && lx + 2 < wn.ww && ly + 2 < wn.wh) {
+            const float* p = lds + ly * wn.ww + lx;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) gv[dy][dx] = p[dy * wn.ww + dx];
+            }
+        } else {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int cx = lx + dx, cy = ly + dy;
+                    float val = 0.0f;
+                    if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
+                        val = lds[cy * wn.ww + cx];
+                    } else {
+                        const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
+                        if (gx >= 0 && gy >= 0) val = Gi[(size_t)gy * g.W + gx];
+                    }
+                    gv[dy][dx] = val;
+                }
+            }
+        }
+        // separable: column sums weighted by ky (and ky*qy), then the kx (and kx*qx) combination
+        float gwx = 0.0f, gwy = 0.0f;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const float qx = (float)(dx - 1) - fx;
+            float cs = 0.0f, csq = 0.0f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float qy = (float)(dy - 1) - fy;
+                const float t = gv[dy][dx] * ky[dy];
+                cs += t; csq += t * qy;
+            }
+            gwx += cs * kx[dx] * qx;
+            gwy += csq * kx[dx];
+        }
+        const float fdt = (float)dt;
+        float* a = accum + ((y - y0) * TS + (x - x0)) * 2;
+        atomicAdd(a, -fdt * gwx);
+        atomicAdd(a + 1, -fdt * gwy);
+    }
+    __syncthreads();
+    float* __restrict__ gT = gTheta + (size_t)it.win * g.H * g.W * 2;
+    const int tw = min(TS, g.W - x0), th = min(TS, g.H - y0);
+    for (int i = threadIdx.x; i < TS * TS * 2; i += NT) {
+        const int c = i & 1, px = (i >> 1) % TS, py = (i >> 1) / TS;
+        const float v = accum[i];
+        if (px < tw && py < th && v != 0.0f) atomicAdd(gT + ((size_t)(y0 + py) * g.W + (x0 + px)) * 2 + c, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mask: event-presence mask (event_utils.py:64-76 / theta_utils.py:59-71).  grid-stride over events.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mask(Geom g, const Item* __restrict__ items, int n_items, const uint32_t* __restrict__ ev_xy,
+                       uint8_t* __restrict__ mask)
+{
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const Item I = items[it];
+        uint8_t* m = mask + (size_t)I.win * g.H * g.W;
+        for (int i = threadIdx.x; i < I.count; i += blockDim.x) {
+            const uint32_t xy = ev_xy[I.begin + i];
+            m[(size_t)(xy >> 16) * g.W + (xy & 0xffff)] = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_tv: total variation of the event-masked flow (regularizers.py:14-38) and its unscaled gradient image.
+//   F = Theta*mask;  TV = 0.25*sum(|Fx*Sx|+|Fx*Sy|+|Fy*Sx|+|Fy*Sy|) / (#pixels with any non-zero term + eps)
+//   tvg[y,x,c] = mask * sum_{S in Sx,Sy} adj_S(sign(F_c * S))         (scaled by 0.25/(count+eps) in k_final)
+// grid (ntiles, B).  tvparts (B,ntiles,2) = {sum of abs, non-zero count}.
+// With unmasked != 0 also accumulates |div Theta| partial (regularizers.py:41-58) into tvparts[...,2].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_tv(Geom g, const double* __restrict__ Theta, const uint8_t* __restrict__ mask,
+                                            double* __restrict__ tvg, double* __restrict__ tvparts, int want_thdiv)
+{
+    constexpr int P2 = TS + 4, P1 = TS + 2;
+    __shared__ double f[2][P2][P2 + 1];
+    __shared__ float sg[4][P1][P1 + 1];       // sign(gx_0), sign(gy_0), sign(gx_1), sign(gy_1)
+    __shared__ double scratch[NWAVE];
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int tx = tile % g.tilesX, ty = tile / g.tilesX;
+    const int x0 = tx * TS, y0 = ty * TS;
+    const double* __restrict__ Th = Theta + (size_t)b * g.H * g.W * 2;
+    const uint8_t* __restrict__ mk = mask + (size_t)b * g.H * g.W;
+    for (int p = threadIdx.x; p < P2 * P2; p += NT) {
+        const int ly = p / P2, lx = p % P2;
+        const int y = y0 + ly - 2, x = x0 + lx - 2;
+        double vx = 0.0, vy = 0.0;
+        if (y >= 0 && y < g.H && x >= 0 && x < g.W && mk[(size_t)y * g.W + x]) {
+            const double2 v = *reinterpret_cast<const double2*>(Th + ((size_t)y * g.W + x) * 2);
+            vx = v.x; vy = v.y;
+        }
+        f[0][ly][lx] = vx; f[1][ly][lx] = vy;
+    }
+    __syncthreads();
+    double sabs = 0.0, cnt = 0.0;
+    for (int p = threadIdx.x; p < P1 * P1; p += NT) {
+        const int ly = p / P1, lx = p % P1;
+        const int y = y0 + ly - 1, x = x0 + lx - 1;
+        const bool in = (y >= 0 && y < g.H && x >= 0 && x < g.W);
+        double g4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (in) {
+            auto a0 = [&](int yy, int xx) -> double { return f[0][yy][xx]; };
+            auto a1 = [&](int yy, int xx) -> double { return f[1][yy][xx]; };
+            scharr_at(a0, ly + 1, lx + 1, g4[0], g4[1]);
+            scharr_at(a1, ly + 1, lx + 1, g4[2], g4[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sg[k][ly][lx] = (g4[k] > 0.0) ? 1.0f : ((g4[k] < 0.0) ? -1.0f : 0.0f);
+        const bool own = in && ly >= 1 && ly <= TS && lx >= 1 && lx <= TS;     // pixel belongs to this tile
+        if (own) {
+            sabs += (fabs(g4[0]) * 0.25 + fabs(g4[1]) * 0.25) + (fabs(g4[2]) * 0.25 + fabs(g4[3]) * 0.25);
+            if (fabs(g4[0]) > 0.0 || fabs(g4[1]) > 0.0 || fabs(g4[2]) > 0.0 || fabs(g4[3]) > 0.0) cnt += 1.0;
+        }
+    }
+    __syncthreads();
+    double* __restrict__ out = tvg + (size_t)b * g.H * g.W * 2;
+    for (int p = threadIdx.x; p < TS * TS; p += NT) {
+        const int ly = p / TS, lx = p % TS;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= g.H || x >= g.W) continue;
+        double o[2] = {0.0, 0.0};
+        if (mk[(size_t)y * g.W + x]) {
+            const int cy = ly + 1, cx = lx + 1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float (*sx)[P1 + 1] = sg[2 * c];
+                const float (*sy)[P1 + 1] = sg[2 * c + 1];
+                const double ax = 3.0 * ((double)sx[cy + 1][cx + 1] - sx[cy + 1][cx - 1]) + 10.0 * ((double)sx[cy][cx + 1] - sx[cy][cx - 1])
+                                + 3.0 * ((double)sx[cy - 1][cx + 1] - sx[cy - 1][cx - 1]);
+                const double ay = 3.0 * ((double)sy[cy + 1][cx + 1] - sy[cy - 1][cx + 1]) + 10.0 * ((double)sy[cy + 1][cx] - sy[cy - 1][cx])
+                                + 3.0 * ((double)sy[cy + 1][cx - 1] - sy[cy - 1][cx - 1]);
+                o[c] = -(ax + ay);
+            }
+        }
+        *reinterpret_cast<double2*>(out + ((size_t)y * g.W + x) * 2) = make_double2(o[0], o[1]);
+    }
+    sabs = block_sum(sabs, scratch);
+    cnt = block_sum(cnt, scratch);
+    double* tp = tvparts + ((size_t)b * g.ntiles + tile) * 3;
+    if (threadIdx.x == 0) { tp[0] = sabs; tp[1] = cnt; tp[2] = 0.0; }
+
+    if (want_thdiv) {
+        // per_pix_theta_divergence (regularizers.py:41-58): UNMASKED Theta
+        __syncthreads();
+        for (int p = threadIdx.x; p < P2 * P2; p += NT) {
+            const int ly = p / P2, lx = p % P2;
+            const int y = y0 + ly - 2, x = x0 + lx - 2;
+            double vx = 0.0, vy = 0.0;
+            if (y >= 0 && y < g.H && x >= 0 && x < g.W) {
+                const double2 v = *reinterpret_cast<const double2*>(Th + ((size_t)y * g.W + x) * 2);
+                vx = v.x; vy = v.y;
+            }
+            f[0][ly][lx] = vx; f[1][ly][lx] = vy;
+        }
+        __syncthreads();
+        // evaluate K (*) s per tile pixel straight from f (5x5 footprint); s = sum of the four Scharr images,
+        // zero outside the image (each 'same' convolution stage is zero padded).  Report-only, so recompute freely.
+        double sum = 0.0;
+        for (int p = threadIdx.x; p < TS * TS; p += NT) {
+            const int ly = p / TS, lx = p % TS;
+            const int y = y0 + ly, x = x0 + lx;
+            if (y >= g.H || x >= g.W) continue;
+            double d = 0.0;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (dy == 0 && dx == 0) continue;
+                    const int yy = y + dy, xx = x + dx;
+                    if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) continue;
+                    auto a0 = [&](int q, int rr) -> double { return f[0][q][rr]; };
+                    auto a1 = [&](int q, int rr) -> double { return f[1][q][rr]; };
+                    double gx0, gy0, gx1, gy1;
+                    scharr_at(a0, ly + 2 + dy, lx + 2 + dx, gx0, gy0);
+                    scharr_at(a1, ly + 2 + dy, lx + 2 + dx, gx1, gy1);
+                    const double kw = (dy != 0 && dx != 0) ? (1.0 / 12.0) : (1.0 / 6.0);
+                    d += kw * (gx0 + gy0 + gx1 + gy1);
+                }
+            }
+            sum += fabs(d);
+        }
+        sum = block_sum(sum, scratch);
+        if (threadIdx.x == 0) tp[2] = sum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_project: dL/dtheta[i,j,c] += sum_{y,x in tile} AH[y,i] AW[x,j] src[y,x,c]   (adjoint of k_theta).
+// grid (ntiles, B, nsrc): z = 0 projects the fp32 event gradient gTheta, z = 1 the fp64 TV gradient image.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w,
+        const double* __restrict__ AH, const double* __restrict__ AW,
+        const int2* __restrict__ rowtap, const int2* __restrict__ coltap,
+        const float* __restrict__ gTheta, const double* __restrict__ tvg,
+        double* __restrict__ gth_main, double* __restrict__ gth_tv)   // (B,h,w,2) each, zeroed
+{
+    __shared__ double scratch[NWAVE];
+    __shared__ int rng[4];
+    const int tile = blockIdx.x, b = blockIdx.y, src = blockIdx.z;
+    const int tx = tile % g.tilesX, ty = tile / g.tilesX;
+    const int x0 = tx * TS, y0 = ty * TS;
+    const int x1 = min(x0 + TS, g.W), y1 = min(y0 + TS, g.H);
+    if (threadIdx.x == 0) {
+        int ilo = h, ihi = 0, jlo = w, jhi = 0;
+        for (int y = y0; y < y1; ++y) { ilo = min(ilo, rowtap[y].x); ihi = max(ihi, rowtap[y].y); }
+        for (int x = x0; x < x1; ++x) { jlo = min(jlo, coltap[x].x); jhi = max(jhi, coltap[x].y); }
+        rng[0] = ilo; rng[1] = ihi; rng[2] = jlo; rng[3] = jhi;
+    }
+    __syncthreads();
+    const int ilo = rng[0], ihi = rng[1], jlo = rng[2], jhi = rng[3];
+    // this thread's pixels (TS*TS/NT = 4 slots; out-of-image slots carry zeros)
+    constexpr int NS = TS * TS / NT;
+    double vx[NS], vy[NS]; int py[NS], px[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int p = threadIdx.x + k * NT;
+        const int y = y0 + p / TS, x = x0 + p % TS;
+        const bool in = (y < g.H && x < g.W);
+        py[k] = in ? y : y0; px[k] = in ? x : x0;
+        vx[k] = 0.0; vy[k] = 0.0;
+        if (in) {
+            const size_t o = ((size_t)b * g.H * g.W + (size_t)y * g.W + x) * 2;
+            if (src == 0) { vx[k] = (double)gTheta[o]; vy[k] = (double)gTheta[o + 1]; }
+            else { vx[k] = tvg[o]; vy[k] = tvg[o + 1]; }
+        }
+    }
+    double* __restrict__ out = (src == 0 ? gth_main : gth_tv) + (size_t)b * h * w * 2;
+    for (int i = ilo; i < ihi; ++i) {
+        for (int j = jlo; j < jhi; ++j) {
+            double sx = 0.0, sy = 0.0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const double wt = AH[(size_t)py[k] * h + i] * AW[(size_t)px[k] * w + j];
+                sx += wt * vx[k]; sy += wt * vy[k];
+            }
+            sx = block_sum(sx, scratch);
+            sy = block_sum(sy, scratch);
+            if (threadIdx.x == 0) {
+                if (sx != 0.0) atomicAdd(out + ((size_t)i * w + j) * 2, sx);
+                if (sy != 0.0) atomicAdd(out + ((size_t)i * w + j) * 2 + 1, sy);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_final: per-window scalar assembly (losses.py:176-203).  grid (B), one workgroup each.
+// Also combines the coarse gradient: grad = gth_main + tv_scale * gth_tv (h*w*2 <= a few thousand values);
+// the dense (identity) gradient is combined by k_final_dense.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
+        const StatPart* __restrict__ parts, const double* __restrict__ divparts, const double* __restrict__ tvparts,
+        const double* __restrict__ tmm, const WinConst* __restrict__ wc,
+        const double* __restrict__ gth_main, const double* __restrict__ gth_tv,
+        OutScal* __restrict__ outs, double* __restrict__ grad_out, int want_grad)
+{
+    __shared__ double scratch[NWAVE];
+    __shared__ double sh_tvscale;
+    const int b = blockIdx.x;
+    const WinConst& c = wc[b];
+    OutScal* __restrict__ o = outs + b;
+    const double HW = (double)g.H * (double)g.W;
+    double sum_rel_con = 0.0, sum_rel_corr = 0.0, sum_rel_div = 0.0;     // live in thread 0
+    for (int r = 0; r < g.R; ++r) {
+        double dsum = 0.0;
+        if (ep.want_div) {
+            double v = 0.0;
+            for (int i = threadIdx.x; i < g.ntiles; i += NT) v += divparts[((size_t)b * g.R + r) * g.ntiles + i];
+            dsum = block_sum(v, scratch);
+        }
+        if (threadIdx.x < 64) {
+            const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.ntiles);
+            if (threadIdx.x == 0) {
+                const double mse = mse_from_moments(s, c.sE[r], c.sEE[r], HW);
+                const double mean = s.sI / HW;
+                const double var = s.sII / HW - mean * mean;
+                const double cgm = s.sG2 / HW;
+                const double con = (ep.contrast_kind == 1) ? var : cgm;
+                const double c0 = (ep.contrast_kind == 1) ? c.c0_var : c.c0_gradmag;
+                const double dv = ep.want_div ? dsum / HW : NAN;
+                o->corr[r] = -mse; o->contrast_gm[r] = cgm; o->var[r] = var; o->div[r] = dv;
+                sum_rel_con += c.mrw[r] * con / (c0 + EPSN);
+                sum_rel_corr += c.mrw[r] * (-mse) / (c.zc[r] + EPSN);
+                if (ep.want_div) sum_rel_div += c.mrw[r] * dv / (c.d0 + EPSN);
+            }
+        }
+    }
+    double tv = 0.0, tvscale = 0.0;
+    if (ep.want_tv) {
+        double a = 0.0, n = 0.0;
+        for (int i = threadIdx.x; i < g.ntiles; i += NT) {
+            a += tvparts[((size_t)b * g.ntiles + i) * 3];
+            n += tvparts[((size_t)b * g.ntiles + i) * 3 + 1];
+        }
+        a = block_sum(a, scratch);
+        n = block_sum(n, scratch);
+        if (threadIdx.x == 0) { tv = a / (n + EPSN); tvscale = ep.gamma * 0.25 / (n + EPSN); }
+    }
+    // a NaN anywhere in theta must surface as a NaN loss (the reference propagates it through the warp)
+    double bad = 0.0;
+    for (int i = threadIdx.x; i < g.ntiles * 4; i += NT) {
+        const double v = tmm[(size_t)b * g.ntiles * 4 + i];
+        if (!(v == v)) bad = 1.0;
+    }
+    bad = block_sum(bad, scratch);
+    if (threadIdx.x == 0) {
+        const double R = (double)g.R;
+        const double mrc = sum_rel_con / R, mrr = sum_rel_corr / R;
+        const double mrd = ep.want_div ? sum_rel_div / R : NAN;
+        const double tv_in_loss = (ep.cur_pyr_lvl <= 0) ? tv : 0.0;
+        double val = (ep.alpha * (-mrc) + ep.beta * (-mrr));
+        double reg = 0.0;
+        if (ep.gamma != 0.0) reg += ep.gamma * tv_in_loss;
+        if (ep.delta != 0.0) reg += ep.delta * mrd;
+        val += reg;
+        if (bad > 0.0) val = NAN;
+        o->mean_rel_contrast = mrc; o->mean_rel_corr = mrr; o->mean_rel_div = mrd;
+        o->tv = (ep.cur_pyr_lvl <= 0) ? (ep.want_tv ? tv : NAN) : 0.0;
+        o->value = val;
+        o->tv_scale = ep.use_tv_grad ? tvscale : 0.0;
+        o->nonfinite = (val - val == 0.0) ? 0.0 : 1.0;
+        o->_pad = 0.0;
+        sh_tvscale = ep.use_tv_grad ? tvscale : 0.0;
+    }
+    __syncthreads();
+    if (want_grad && !ep.identity) {
+        const double s = sh_tvscale;
+        const int n = ep.h * ep.w * 2;
+        for (int i = threadIdx.x; i < n; i += NT) {
+            double v = gth_main[(size_t)b * n + i];
+            if (ep.use_tv_grad) v += s * gth_tv[(size_t)b * n + i];
+            grad_out[(size_t)b * n + i] = v;
+        }
+    }
+}
+
+// dense (identity resample) gradient: grad = (double)gTheta + tv_scale * tvg.  grid-stride, grid (nblk, B)
+__global__ void k_final_dense(Geom g, int use_tv, const float* __restrict__ gTheta, const double* __restrict__ tvg,
+                              const OutScal* __restrict__ outs, double* __restrict__ grad_out)
+{
+    const int b = blockIdx.y;
+    const size_t n = (size_t)g.H * g.W * 2;
+    const double s = outs[b].tv_scale;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double v = (double)gTheta[b * n + i];
+        if (use_tv) v += s * tvg[b * n + i];
+        grad_out[b * n + i] = v;
+    }
+}
+
+}  // namespace eincm

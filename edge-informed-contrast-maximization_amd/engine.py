@@ -1,0 +1,202 @@
+"""Python handle on one eincm_ctx (include/eincm.h): a batch of event windows resident on one MI355X."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class EincmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'eincm error {code}: {msg}')
+        self.code = code
+
+
+class NonFiniteLoss(EincmError):
+    pass
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def make_params(alpha, beta, gamma, delta, cur_pyr_lvl, method='bilinear', contrast_kind=L.CONTRAST_GRAD_MAG,
+                full_aux=False):
+    if isinstance(method, str):
+        if method not in L.METHODS:
+            raise ValueError(f'scale_to_sensor_size_method {method!r} not supported; one of {sorted(L.METHODS)}')
+        method = L.METHODS[method]
+    return L.Params(float(alpha), float(beta), float(gamma), float(delta), int(cur_pyr_lvl), int(method),
+                    int(contrast_kind), L.PF_FULL_AUX if full_aux else 0)
+
+
+class Engine:
+    """One GPU context.  ``set_windows`` stages a batch of B independent windows (B = 1 for the reference's
+    single-window solver, solver.py:185-194); ``loss_grad`` evaluates value_and_grad(loss_func) for all of them."""
+
+    def __init__(self, sensor_size, max_events_total, max_refs=8, max_windows=1, device=0, timing=False):
+        self._lib = L.load()
+        self.H, self.W = int(sensor_size[0]), int(sensor_size[1])
+        self.max_windows = int(max_windows)
+        self.max_refs = int(max_refs)
+        self._ctx = self._lib.eincm_create(int(device), self.H, self.W, int(max_refs), int(max_windows),
+                                           int(max_events_total), L.CF_TIMING if timing else 0)
+        if not self._ctx:
+            raise EincmError(L.ERR_HIP, self._lib.eincm_last_error(None).decode())
+        self.B = 0
+        self.R = 0
+        self.timing = bool(timing)
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, '_ctx', None):
+            self._lib.eincm_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, allow_nonfinite=False):
+        if rc == L.OK:
+            return
+        msg = self._lib.eincm_last_error(self._ctx).decode()
+        if rc == L.ERR_NONFINITE:
+            if allow_nonfinite:
+                return
+            raise NonFiniteLoss(rc, msg)
+        raise EincmError(rc, msg)
+
+    # -- staging ----------------------------------------------------------------------------------
+    def set_windows(self, windows):
+        """windows: list of (xs, ys, ts, edges, edge_ts) tuples (the reference's datasample tuple)."""
+        B = len(windows)
+        R = len(np.atleast_1d(windows[0][4]))
+        n = np.array([len(w[0]) for w in windows], dtype=np.int64)
+        xs = np.ascontiguousarray(np.concatenate([np.asarray(w[0]).astype(np.int16, copy=False) for w in windows]))
+        ys = np.ascontiguousarray(np.concatenate([np.asarray(w[1]).astype(np.int16, copy=False) for w in windows]))
+        ts = np.ascontiguousarray(np.concatenate([np.asarray(w[2], dtype=np.float64) for w in windows]))
+        edges = np.ascontiguousarray(np.stack([np.asarray(w[3], dtype=np.float64) for w in windows]))
+        edge_ts = np.ascontiguousarray(np.stack([np.atleast_1d(np.asarray(w[4], dtype=np.float64)) for w in windows]))
+        if edges.shape != (B, R, self.H, self.W):
+            raise ValueError(f'edges must be (R,{self.H},{self.W}) per window, got {edges.shape[1:]}')
+        if edge_ts.shape != (B, R):
+            raise ValueError('every window needs the same number of reference times')
+        if xs.size == 0:
+            xs = np.zeros(1, np.int16); ys = np.zeros(1, np.int16); ts = np.zeros(1, np.float64)
+        rc = self._lib.eincm_set_windows(self._ctx, B, R, n.ctypes.data_as(C.POINTER(C.c_int64)),
+                                         xs.ctypes.data_as(C.POINTER(C.c_int16)), ys.ctypes.data_as(C.POINTER(C.c_int16)),
+                                         _dp(ts), _dp(edges), _dp(edge_ts))
+        self._check(rc)
+        self.B, self.R = B, R
+        self.n_events = n
+
+    def set_window(self, xs, ys, ts, edges, edge_ts):
+        self.set_windows([(xs, ys, ts, edges, edge_ts)])
+
+    # -- evaluation -------------------------------------------------------------------------------
+    def loss_grad(self, theta, params, want_grad=True, want_aux=False, allow_nonfinite=True):
+        """theta: (B,h,w,2) or (h,w,2) when B == 1.  Returns (value (B,), grad (B,h,w,2) | None, aux list | None)."""
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64))
+        if th.ndim == 3:
+            th = th[None]
+        if th.ndim != 4 or th.shape[0] != self.B or th.shape[3] != 2:
+            raise ValueError(f'theta must be ({self.B},h,w,2), got {th.shape}')
+        _, h, w, _ = th.shape
+        value = np.empty(self.B, dtype=np.float64)
+        grad = np.empty_like(th) if want_grad else None
+        aux = (L.Aux * self.B)() if want_aux else None
+        rc = self._lib.eincm_loss_grad(self._ctx, _dp(th), h, w, C.byref(params), _dp(value),
+                                       _dp(grad) if want_grad else None, aux)
+        self._check(rc, allow_nonfinite)
+        auxl = None
+        if want_aux:
+            auxl = [{k: getattr(a, k) for k, _ in L.Aux._fields_} for a in aux]
+        return value, grad, auxl
+
+    def handover_loss_grad(self, alpha_handover, prev_theta, theta, params, want_grad=True, allow_nonfinite=True):
+        pt = np.ascontiguousarray(np.asarray(prev_theta, dtype=np.float64))
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64))
+        if th.ndim == 3:
+            th, pt = th[None], pt[None]
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha_handover, dtype=np.float64), (self.B,)))
+        _, h, w, _ = th.shape
+        value = np.empty(self.B)
+        dv = np.empty(self.B) if want_grad else None
+        rc = self._lib.eincm_handover_loss_grad(self._ctx, _dp(a), _dp(pt), _dp(th), h, w, C.byref(params), _dp(value),
+                                                _dp(dv) if want_grad else None)
+        self._check(rc, allow_nonfinite)
+        return value, dv
+
+    def objectives(self, Theta):
+        """compute_loss_objectives (losses.py:49-105) on full-resolution Theta (B,H,W,2); list of dicts."""
+        T = np.ascontiguousarray(np.asarray(Theta, dtype=np.float64))
+        if T.ndim == 3:
+            T = T[None]
+        if T.shape != (self.B, self.H, self.W, 2):
+            raise ValueError(f'Theta must be ({self.B},{self.H},{self.W},2), got {T.shape}')
+        out = (L.ObjectivesOut * self.B)()
+        rc = self._lib.eincm_objectives(self._ctx, _dp(T), out)
+        self._check(rc, True)
+        res = []
+        for o in out:
+            d = {}
+            for k, t in L.ObjectivesOut._fields_:
+                if k in ('n_refs', '_pad'):
+                    continue
+                v = getattr(o, k)
+                d[k] = np.array(v[:o.n_refs]) if t is L._A else float(v)
+            res.append(d)
+        return res
+
+    # -- device images ----------------------------------------------------------------------------
+    def iwes(self):
+        a = np.empty((self.B, self.R, self.H, self.W), dtype=np.float32)
+        self._check(self._lib.eincm_get_iwes(self._ctx, a.ctypes.data_as(C.POINTER(C.c_float))))
+        return a
+
+    def zero_iwe(self):
+        a = np.empty((self.B, self.H, self.W), dtype=np.float32)
+        self._check(self._lib.eincm_get_zero_iwe(self._ctx, a.ctypes.data_as(C.POINTER(C.c_float))))
+        return a
+
+    def image_grad(self):
+        a = np.empty((self.B, self.R, self.H, self.W), dtype=np.float32)
+        self._check(self._lib.eincm_get_image_grad(self._ctx, a.ctypes.data_as(C.POINTER(C.c_float))))
+        return a
+
+    def scaled_theta(self):
+        a = np.empty((self.B, self.H, self.W, 2), dtype=np.float64)
+        self._check(self._lib.eincm_get_scaled_theta(self._ctx, _dp(a)))
+        return a
+
+    def timings(self):
+        t = L.Timings()
+        self._check(self._lib.eincm_get_timings(self._ctx, C.byref(t)))
+        d = {n: float(t.ms[i]) for i, n in enumerate(L.STAGE_NAMES)}
+        d['total'] = float(t.total_ms)
+        return d
+
+
+def multi_ref_weights(n_refs):
+    w = np.empty(n_refs)
+    rc = L.load().eincm_multi_ref_weights(int(n_refs), _dp(w))
+    if rc:
+        raise EincmError(rc, 'eincm_multi_ref_weights')
+    return w
+
+
+def resample_matrix(n_in, n_out, method='bilinear'):
+    A = np.empty((n_out, n_in))
+    rc = L.load().eincm_resample_matrix(int(n_in), int(n_out), L.METHODS[method], _dp(A))
+    if rc:
+        raise EincmError(rc, 'eincm_resample_matrix')
+    return A

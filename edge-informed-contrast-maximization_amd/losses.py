@@ -1,0 +1,112 @@
+"""Host-side mirror of the reference's objective callables, backed by the HIP engine.
+
+Same names, argument order and meaning as /root/reference/src/eincm/losses.py:
+    loss_func(theta, xs, ys, ts, edges, edge_ts, alpha, beta, gamma, delta, cur_pyr_lvl, n_pyr_lvls,
+              sensor_size, scale_to_sensor_size_method) -> (final_loss, aux_info)          losses.py:108-205
+    handover_loss_func(alpha_handover, prev_theta, theta, xs, ..., method) -> loss          losses.py:208-276
+    compute_loss_objectives(theta, xs, ys, ts, edges, edge_ts, sensor_size) -> dict         losses.py:49-105
+so the hydra plugin point (configs/theta_loss_func/default.yaml:1-2, ``_target_: eincm.losses.loss_func``)
+can name this module instead.  The reference differentiates ``loss_func`` with JAX inside jaxopt; a HIP
+engine cannot be traced, so the gradient is exposed explicitly as ``value_and_grad_loss_func`` /
+``value_and_grad_handover_loss_func`` (what jax.value_and_grad would return) and consumed by
+``solver.ScipyMinimize``.
+
+The event window is staged on the GPU once and reused for every evaluation, like the reference's closed-over
+device-resident ``*args``: engines are cached by the identity of the (xs, ys, ts, edges, edge_ts) arrays.
+"""
+import weakref
+
+import numpy as np
+
+from . import _lib as L
+from .engine import Engine, make_params
+
+_CACHE = []            # [(refs tuple, key, Engine)] most-recent first
+_CACHE_SIZE = 2
+
+
+def _as_np(a):
+    return a if isinstance(a, np.ndarray) else np.asarray(a)
+
+
+def engine_for(xs, ys, ts, edges, edge_ts, sensor_size, device=0):
+    """Engine holding this window (staged on first use; reused while the same array objects are passed)."""
+    arrs = tuple(_as_np(a) for a in (xs, ys, ts, edges, edge_ts))
+    key = (tuple(int(s) for s in sensor_size), device) + tuple((a.shape, a.dtype.str) for a in arrs)
+    for i, (refs, k, eng) in enumerate(_CACHE):
+        if k == key and all(r() is a for r, a in zip(refs, arrs)):
+            if i:
+                _CACHE.insert(0, _CACHE.pop(i))
+            return eng
+    eng = Engine(sensor_size, max_events_total=max(len(arrs[0]), 1), max_refs=max(len(np.atleast_1d(arrs[4])), 1),
+                 max_windows=1, device=device)
+    eng.set_window(*arrs)
+    try:
+        refs = tuple(weakref.ref(a) for a in arrs)
+    except TypeError:       # not weak-referenceable (e.g. a list was converted): do not cache
+        return eng
+    _CACHE.insert(0, (refs, key, eng))
+    while len(_CACHE) > _CACHE_SIZE:
+        _CACHE.pop()[2].close()
+    return eng
+
+
+def clear_engine_cache():
+    while _CACHE:
+        _CACHE.pop()[2].close()
+
+
+def _aux_dict(eng, a, with_arrays):
+    d = {'final_loss': a['final_loss'], 'mean_rel_corr': a['mean_rel_corr'], 'mean_rel_contrast': a['mean_rel_contrast'],
+         'mean_rel_iwe_divergence': a['mean_rel_iwe_divergence'], 'theta_total_variation': a['theta_total_variation']}
+    if with_arrays:
+        from .engine import multi_ref_weights
+        d['scaled_theta'] = eng.scaled_theta()[0]
+        d['multi_ref_weights'] = multi_ref_weights(eng.R)
+    return d
+
+
+def value_and_grad_loss_func(theta, xs, ys, ts, edges, edge_ts, alpha, beta, gamma, delta, cur_pyr_lvl, n_pyr_lvls,
+                             sensor_size, scale_to_sensor_size_method='bilinear', contrast_kind=L.CONTRAST_GRAD_MAG,
+                             full_aux=False, aux_arrays=False):
+    """((final_loss, aux_info), grad) — the shape jax.value_and_grad(loss_func, has_aux=True) returns."""
+    eng = engine_for(xs, ys, ts, edges, edge_ts, sensor_size)
+    p = make_params(alpha, beta, gamma, delta, cur_pyr_lvl, scale_to_sensor_size_method, contrast_kind, full_aux)
+    v, g, aux = eng.loss_grad(np.asarray(theta, dtype=np.float64), p, want_grad=True, want_aux=True)
+    return (float(v[0]), _aux_dict(eng, aux[0], aux_arrays)), g[0]
+
+
+def loss_func(theta, xs, ys, ts, edges, edge_ts, alpha, beta, gamma, delta, cur_pyr_lvl, n_pyr_lvls, sensor_size,
+              scale_to_sensor_size_method='bilinear', contrast_kind=L.CONTRAST_GRAD_MAG):
+    """(final_loss, aux_info) as losses.py:108-205; forward only, every aux entry evaluated."""
+    eng = engine_for(xs, ys, ts, edges, edge_ts, sensor_size)
+    p = make_params(alpha, beta, gamma, delta, cur_pyr_lvl, scale_to_sensor_size_method, contrast_kind, True)
+    v, _, aux = eng.loss_grad(np.asarray(theta, dtype=np.float64), p, want_grad=False, want_aux=True)
+    return float(v[0]), _aux_dict(eng, aux[0], True)
+
+
+def value_and_grad_handover_loss_func(alpha_handover, prev_theta, theta, xs, ys, ts, edges, edge_ts, alpha, beta, gamma,
+                                      delta, cur_pyr_lvl, n_pyr_lvls, sensor_size, scale_to_sensor_size_method='bilinear',
+                                      contrast_kind=L.CONTRAST_GRAD_MAG):
+    """(loss, d loss / d alpha_handover) of losses.py:269-276."""
+    eng = engine_for(xs, ys, ts, edges, edge_ts, sensor_size)
+    p = make_params(alpha, beta, gamma, delta, cur_pyr_lvl, scale_to_sensor_size_method, contrast_kind, False)
+    v, dv = eng.handover_loss_grad(float(np.asarray(alpha_handover).reshape(-1)[0]), prev_theta, theta, p, want_grad=True)
+    return float(v[0]), float(dv[0])
+
+
+def handover_loss_func(alpha_handover, prev_theta, theta, xs, ys, ts, edges, edge_ts, alpha, beta, gamma, delta,
+                       cur_pyr_lvl, n_pyr_lvls, sensor_size, scale_to_sensor_size_method='bilinear',
+                       contrast_kind=L.CONTRAST_GRAD_MAG):
+    """loss only, as losses.py:208-276."""
+    eng = engine_for(xs, ys, ts, edges, edge_ts, sensor_size)
+    p = make_params(alpha, beta, gamma, delta, cur_pyr_lvl, scale_to_sensor_size_method, contrast_kind, False)
+    v, _ = eng.handover_loss_grad(float(np.asarray(alpha_handover).reshape(-1)[0]), prev_theta, theta, p, want_grad=False)
+    return float(v[0])
+
+
+def compute_loss_objectives(theta, xs, ys, ts, edges, edge_ts, sensor_size):
+    """losses.py:49-105 on a full-resolution theta (H,W,2).  Per-event ``warped_xs/ys`` are not returned (they
+    never leave the GPU); every scalar key of the reference dict is."""
+    eng = engine_for(xs, ys, ts, edges, edge_ts, sensor_size)
+    return eng.objectives(np.asarray(theta, dtype=np.float64))[0]

@@ -1,0 +1,170 @@
+/* eincm.h — C-ABI of libeincm_hip.so: the MI355X (gfx950) EINCM objective-and-gradient engine.
+ *
+ * Drop-in boundary for ONE path of robotic-vision-lab/Edge-Informed-Contrast-Maximization:
+ *     loss(theta, events, edge_maps) -> (value, grad)
+ * i.e. eincm.losses.loss_func (src/eincm/losses.py:108-205) and the gradient the reference obtains through
+ * jaxopt.ScipyMinimize(jit=True) -> jax.value_and_grad (src/eincm/solver.py:165-173).  The reference has no
+ * FFI of its own (pure Python on JAX); the binding a maintainer would add is a ctypes stub, shown in
+ * INTEGRATION.md.  Plain pointers and sizes only; no torch / HIP types cross this boundary.
+ *
+ * Conventions
+ *   - all host arrays are C-order (row major), caller-owned; nothing is retained after a call returns
+ *   - theta / grad / value / ts / edges / edge_ts are double (the SciPy side of the reference is float64,
+ *     SURVEY 8b); x, y are int16 (the reference's event wire format, exp_mgr.py:283-284)
+ *   - a context is NOT thread-safe; one context per (GPU, caller thread); every call is synchronous
+ *   - return value: 0 = ok, < 0 = error (see EINCM_ERR_*); eincm_last_error() gives the message
+ */
+#ifndef EINCM_H
+#define EINCM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EINCM_ABI_VERSION 1
+
+#define EINCM_OK               0
+#define EINCM_ERR_ARG         -1   /* bad argument (shape, null pointer, out-of-range event coordinate) */
+#define EINCM_ERR_HIP         -2   /* HIP runtime error (message holds hipGetErrorString) */
+#define EINCM_ERR_STATE       -3   /* call out of order (e.g. loss_grad before set_windows) */
+#define EINCM_ERR_NONFINITE   -4   /* loss or gradient is NaN/Inf (outputs are still written) */
+#define EINCM_ERR_UNSUPPORTED -5   /* valid request this build does not implement */
+
+/* contrast objective: 0 = mean squared Scharr gradient magnitude of the raw IWE (losses.py:70, the reference's
+ * live objective); 1 = variance of the IWE (contrast_objectives.py:29-39; BASELINE config "variance-only") */
+#define EINCM_CONTRAST_GRAD_MAG 0
+#define EINCM_CONTRAST_VARIANCE 1
+
+/* scale_to_sensor_size_method (theta_utils.py:25-35 -> jax.image.scale_and_translate kernels) */
+#define EINCM_METHOD_BILINEAR 0    /* 'linear' / 'bilinear' / 'triangle' */
+#define EINCM_METHOD_LANCZOS3 1
+#define EINCM_METHOD_LANCZOS5 2
+#define EINCM_METHOD_CUBIC    3    /* 'cubic' / 'bicubic' */
+
+/* eincm_params.flags */
+#define EINCM_PF_FULL_AUX   1u     /* also evaluate the report-only terms: IWE divergence (losses.py:79-81),
+                                      TV at any gamma (losses.py:75), FWL (losses.py:84) */
+
+/* eincm_create flags */
+#define EINCM_CF_TIMING     1u     /* bracket every kernel with HIP events (eincm_get_timings) */
+
+typedef struct eincm_ctx eincm_ctx;
+
+/* The keyword arguments hydra binds to loss_func (configs/theta_loss_func/default.yaml:1-9) */
+typedef struct eincm_params {
+    double   alpha;          /* contrast weight            losses.py:116 */
+    double   beta;           /* correlation weight         losses.py:117 */
+    double   gamma;          /* total-variation weight     losses.py:118 (live only if cur_pyr_lvl <= 0, :171) */
+    double   delta;          /* IWE-divergence weight      losses.py:119 */
+    int32_t  cur_pyr_lvl;    /* losses.py:120 */
+    int32_t  method;         /* EINCM_METHOD_*             losses.py:123 */
+    int32_t  contrast_kind;  /* EINCM_CONTRAST_* */
+    uint32_t flags;          /* EINCM_PF_* */
+} eincm_params;
+
+/* aux_info of loss_func (losses.py:195-203) without the two arrays (scaled_theta: eincm_get_scaled_theta,
+ * multi_ref_weights: eincm_multi_ref_weights) */
+typedef struct eincm_aux {
+    double final_loss;
+    double mean_rel_corr;
+    double mean_rel_contrast;
+    double mean_rel_iwe_divergence;   /* NaN unless EINCM_PF_FULL_AUX or delta != 0 */
+    double theta_total_variation;     /* 0 if cur_pyr_lvl > 0; NaN if cur_pyr_lvl <= 0, gamma == 0 and no FULL_AUX */
+} eincm_aux;
+
+/* per-reference-time scalars of compute_loss_objectives (losses.py:89-105); arrays are [EINCM_MAX_REFS] */
+#define EINCM_MAX_REFS 16
+typedef struct eincm_objectives_out {
+    int32_t n_refs;
+    int32_t _pad;
+    double correlations[EINCM_MAX_REFS];
+    double zero_correlations[EINCM_MAX_REFS];
+    double rel_correlations[EINCM_MAX_REFS];
+    double contrasts[EINCM_MAX_REFS];
+    double zero_contrast;
+    double rel_contrasts[EINCM_MAX_REFS];
+    double theta_total_variation;
+    double theta_divergence;
+    double iwe_divergences[EINCM_MAX_REFS];
+    double zero_iwe_divergence;
+    double rel_iwe_divergences[EINCM_MAX_REFS];
+    double flow_warp_losses[EINCM_MAX_REFS];
+    double multi_ref_weights[EINCM_MAX_REFS];
+    double variances[EINCM_MAX_REFS];          /* extra: var(IWE_r) (contrast_kind = variance) */
+    double zero_variance;
+} eincm_objectives_out;
+
+/* device time of the last eincm_loss_grad call, per kernel, from HIP events on the engine's stream */
+#define EINCM_N_STAGES 10
+typedef struct eincm_timings {
+    float ms[EINCM_N_STAGES];   /* index = EINCM_STAGE_* ; 0 when the stage did not run */
+    float total_ms;             /* first kernel start -> results on host */
+} eincm_timings;
+#define EINCM_STAGE_CLEAR   0
+#define EINCM_STAGE_THETA   1   /* theta upsample + per-tile velocity bounds */
+#define EINCM_STAGE_SPLAT   2   /* warp + 3x3 Gaussian splat -> IWE stack (dominant) */
+#define EINCM_STAGE_STATS   3   /* min/max/moments/contrast reductions */
+#define EINCM_STAGE_IMGRAD  4   /* dL/dIWE image */
+#define EINCM_STAGE_GATHER  5   /* backward gather -> dL/dTheta */
+#define EINCM_STAGE_TV      6
+#define EINCM_STAGE_PROJECT 7   /* adjoint resample dL/dTheta -> dL/dtheta */
+#define EINCM_STAGE_FINAL   8
+#define EINCM_STAGE_COPY    9
+
+int         eincm_abi_version(void);
+const char* eincm_last_error(const eincm_ctx* ctx);   /* ctx may be NULL: error of the last failed eincm_create */
+
+/* One context = one GPU + one stream + capacity for a batch of up to max_windows independent event windows
+ * of one sensor size (H, W), each with the same number of reference times.  Windows are what
+ * MultipleLevelEINCMSolver.set_datasample holds (solver.py:185-194). */
+eincm_ctx*  eincm_create(int device, int H, int W, int max_refs, int max_windows, int64_t max_events_total,
+                         uint32_t flags);
+void        eincm_destroy(eincm_ctx* ctx);
+
+/* Stage a batch of windows (replaces solver.set_datasample + the theta-independent half of
+ * compute_loss_objectives, losses.py:54-55,66,71,80): copies events/edges to HBM, bins events by source
+ * tile, and evaluates the zero-warp constants (IUE, its contrast / variance / divergence, zero_corrs).
+ *   n_events[b]            events in window b (sum <= max_events_total)
+ *   xs, ys, ts             windows concatenated, sum(n_events) entries; 0 <= x < W, 0 <= y < H
+ *   edges                  (n_windows, n_refs, H, W); edge_ts (n_windows, n_refs)                      */
+int eincm_set_windows(eincm_ctx* ctx, int n_windows, int n_refs, const int64_t* n_events,
+                      const int16_t* xs, const int16_t* ys, const double* ts,
+                      const double* edges, const double* edge_ts);
+
+/* value_and_grad(loss_func) for every staged window (losses.py:108-205 + its reverse pass).
+ *   theta  (n_windows, h, w, 2)     value (n_windows)     grad (n_windows, h, w, 2) or NULL (forward only)
+ *   aux    (n_windows) or NULL                                                                         */
+int eincm_loss_grad(eincm_ctx* ctx, const double* theta, int h, int w, const eincm_params* p,
+                    double* value, double* grad, eincm_aux* aux);
+
+/* handover_loss_func (losses.py:208-276) and d/d(alpha_handover) = <dL/dtheta_ho, prev - theta>:
+ *   theta_ho = a*prev_theta + (1-a)*theta;  a (n_windows), value (n_windows), dvalue_da (n_windows) or NULL */
+int eincm_handover_loss_grad(eincm_ctx* ctx, const double* alpha_handover, const double* prev_theta,
+                             const double* theta, int h, int w, const eincm_params* p,
+                             double* value, double* dvalue_da);
+
+/* compute_loss_objectives (losses.py:49-105) on a full-resolution Theta (n_windows, H, W, 2): forward only. */
+int eincm_objectives(eincm_ctx* ctx, const double* Theta, eincm_objectives_out* out /* n_windows */);
+
+/* Device images of the last evaluation, copied to host (parity tests / plotting):
+ *   iwes (n_windows, n_refs, H, W) float;  zero_iwe (n_windows, H, W) float;
+ *   image_grad = dL/dIWE (n_windows, n_refs, H, W) float;  scaled_theta (n_windows, H, W, 2) double   */
+int eincm_get_iwes(eincm_ctx* ctx, float* iwes);
+int eincm_get_zero_iwe(eincm_ctx* ctx, float* zero_iwe);
+int eincm_get_image_grad(eincm_ctx* ctx, float* image_grad);
+int eincm_get_scaled_theta(eincm_ctx* ctx, double* scaled_theta);
+
+/* compute_weights_for_multi_reference (losses.py:39-46) */
+int eincm_multi_ref_weights(int n_refs, double* w);
+
+/* weight matrix of jax.image.scale_and_translate along one axis (theta_utils.py:25-35): A (n_out, n_in) */
+int eincm_resample_matrix(int n_in, int n_out, int method, double* A);
+
+int eincm_get_timings(eincm_ctx* ctx, eincm_timings* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EINCM_H */
