@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — EINCM loss+grad throughput on MI355X (contract: see the task statement / DESIGN.md "Measurement").
+
+A step = ONE value_and_grad(loss_func) evaluation of this rank's batch of independent event windows (inputs already
+resident in HBM), followed for N > 1 by the RCCL all-reduce of the scalar batch loss.  Workload at N = 1: the
+per-GPU share of BASELINE.json config C4 — 8 MVSEC-shape windows (260x346), 1e6 events each, 5 reference times,
+2-DoF theta, full EINCM objective (contrast + edge correlation), alpha=20 beta=35 — which is the configuration the
+metric "warped-events/sec/GPU ... 1e6 events @ 346x260" is quoted on.  Weak scaling: every rank holds its own 8 windows.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+
+
+def algorithmic_bytes(N, R, H, W, dense_theta):
+    """minimum compulsory HBM traffic of one evaluation of one window (events packed 8 B, read once
+    forward + once backward; IWE write/read, edge read, dL/dIWE write/read; Theta/grad for dense theta)."""
+    return 2 * 8 * N + R * H * W * 4 * 5 + (H * W * 2 * 4 * 2 if dense_theta else 0)
+
+
+def splat_algorithmic_bytes(N, R, H, W):
+    """Dominant kernel (k_splat): events in once (8 B each) + the R IWE images out (fp32)."""
+    return 8 * N + 4 * R * H * W
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--windows-per-gpu', type=int, default=8)
+    ap.add_argument('--events', type=int, default=1_000_000)
+    ap.add_argument('--refs', type=int, default=5)
+    ap.add_argument('--sensor', type=str, default='260x346')
+    ap.add_argument('--theta', type=str, default='1x1', help='hxw of theta, or "dense"')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-latency', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=dev)
+
+    import __graft_entry__ as ge
+    ge.build()
+    synth = importlib.import_module('edge-informed-contrast-maximization_amd.synth')
+    engine = importlib.import_module('edge-informed-contrast-maximization_amd.engine')
+    sharding = importlib.import_module('edge-informed-contrast-maximization_amd.sharding')
+
+    H, W = (int(v) for v in a.sensor.split('x'))
+    B, N, R = a.windows_per_gpu, a.events, a.refs
+    dense = a.theta == 'dense'
+    h, w = (H, W) if dense else (int(v) for v in a.theta.split('x'))
+    alpha, beta = 20.0, 35.0            # configs/main.yaml:16-17
+
+    # ---- synthetic windows, resident in HBM before the timed region ----
+    wins = [synth.make_window(1000 * rank + b, (H, W), N, R, flow='smooth' if dense else 'constant', flow_mag=20.0)
+            for b in range(B)]
+    if dense:
+        base = np.stack([wn['flow_gt'] for wn in wins])
+    else:
+        base = np.stack([synth.theta_near_truth(1000 * rank + b, wn, (h, w)) for b, wn in enumerate(wins)])
+    n_theta = a.steps + a.warmup
+    eng = engine.Engine((H, W), B * N, max_refs=R, max_windows=B, device=local_rank, timing=True)
+    t0 = time.perf_counter()
+    eng.set_windows([(wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts']) for wn in wins])
+    t_stage = time.perf_counter() - t0
+    p = engine.make_params(alpha, beta, 0.0, 0.0, 4 if not dense else 0)
+
+    def theta_at(k):                    # theta changes every call: nothing but the window constants is reusable
+        return base * (1.0 + 0.01 * ((k % 7) - 3))
+
+    def step(k):
+        v, g, _ = eng.loss_grad(theta_at(k), p)
+        tot = sharding.allreduce_batch_loss(v, dev) if world > 1 else float(v.sum())
+        return tot, v, g
+
+    for k in range(a.warmup):
+        step(k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    stage_acc = {}
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        tot, v, g = step(a.warmup + k)
+        for kk, vv in eng.timings().items():
+            stage_acc[kk] = stage_acc.get(kk, 0.0) + vv
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert np.all(np.isfinite(v)) and np.all(np.isfinite(g)), 'non-finite loss/grad in the timed region'
+
+    ms_per_step = elapsed / a.steps * 1e3
+    warped = world * B * N * R           # warped events per step, all ranks
+    value = warped / (elapsed / a.steps)
+
+    out = None
+    if rank == 0:
+        splat_ms = stage_acc.get('splat', 0.0) / a.steps
+        gather_ms = stage_acc.get('gather', 0.0) / a.steps
+        splat_bytes = B * splat_algorithmic_bytes(N, R, H, W)
+        achieved = splat_bytes / (splat_ms * 1e-3) / 1e9 if splat_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        wl = f'{B}x[{H}x{W} N={N} R={R} theta={a.theta}]'
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(wl, {}).get('k_splat_hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        eval_bytes = B * algorithmic_bytes(N, R, H, W, dense)
+        out = {
+            'metric': 'warped-events/sec/GPU + loss+grad eval ms, 1e6 events @ 346x260',
+            'value': value, 'unit': 'warped-events/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'C4 share per GPU: {wl}, EINCM contrast+edge-correlation loss+grad, alpha=20 beta=35',
+                       'windows_per_gpu': B, 'events_per_window': N, 'n_refs': R, 'sensor': [H, W],
+                       'theta': [h, w, 2], 'parallelism': f'window-parallel x{world}, scalar-loss all-reduce'},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_splat', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': splat_bytes, 'avg_launch_ms': splat_ms},
+            'eval_roofline': {'achieved': eval_bytes / (ms_per_step * 1e-3) / 1e9, 'unit': 'GB/s',
+                              'frac': eval_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                              'algorithmic_bytes_per_step': eval_bytes},
+            'stage_ms_per_step': {k: round(vv / a.steps, 4) for k, vv in stage_acc.items()},
+            'set_windows_s': t_stage,
+            'warped_events_per_s_per_gpu': value / world,
+        }
+    eng.close()
+
+    # ---- single-window latency (second half of the metric: loss+grad eval ms at 1e6 events) ----
+    if rank == 0 and not a.no_latency:
+        wn = wins[0]
+        with engine.Engine((H, W), N, max_refs=R, max_windows=1, device=local_rank) as e1:
+            e1.set_window(wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts'])
+            for k in range(3):
+                e1.loss_grad(theta_at(k)[0], p)
+            ts = []
+            for k in range(30):
+                t0 = time.perf_counter(); e1.loss_grad(theta_at(k)[0], p); ts.append(time.perf_counter() - t0)
+        out['eval_ms_single_window'] = float(np.median(ts) * 1e3)
+        out['warped_events_per_s_single_window'] = N * R / float(np.median(ts))
+
+    # ---- CPU baseline: the fp64 numpy oracle (a port of the reference arithmetic; the reference itself cannot run) ----
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import eincm_oracle as O
+        wn = wins[0]
+        n_eval, t_cpu = 0, 0.0
+        while t_cpu < 10.0 and n_eval < 8:
+            t0 = time.perf_counter()
+            O.loss_and_grad(theta_at(n_eval)[0], wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts'], alpha, beta, 0.0, 0.0,
+                            4 if not dense else 0, 5, (H, W))
+            t_cpu += time.perf_counter() - t0
+            n_eval += 1
+        out['cpu_baseline'] = {'value': n_eval * N * R / t_cpu, 'unit': 'warped-events/s', 'cores': 1, 'kind': 'port',
+                               'sample': f'{n_eval} loss+grad evaluations of 1 window ({H}x{W}, N={N}, R={R}) by the numpy fp64 '
+                                         f'oracle, {t_cpu:.1f} s', 'eval_ms': t_cpu / n_eval * 1e3,
+                               'host_cores_available': os.cpu_count()}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

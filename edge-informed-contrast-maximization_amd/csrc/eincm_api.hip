@@ -253,7 +253,8 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity) {
     }
     {
         StageTimer t(c, EINCM_STAGE_SPLAT);
-        hipLaunchKernelGGL(k_splat, dim3(c->n_items, g.R), dim3(NT), WIN_CAP * sizeof(float), c->stream, g, c->d_items,
+        if (c->n_items > 0)
+            hipLaunchKernelGGL(k_splat, dim3(c->n_items, g.R), dim3(NT), WIN_CAP * sizeof(float), c->stream, g, c->d_items,
                            c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe);
     }
     {
@@ -338,7 +339,8 @@ int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_p
         {
             StageTimer t(c, EINCM_STAGE_GATHER);
             HIPCHK(c, hipMemsetAsync(c->d_gTheta, 0, (size_t)g.B * img * 2 * sizeof(float), c->stream));
-            hipLaunchKernelGGL(k_gather, dim3(c->n_items, g.R), dim3(NT), (WIN_CAP + TS * TS * 2) * sizeof(float), c->stream,
+            if (c->n_items > 0)
+                hipLaunchKernelGGL(k_gather, dim3(c->n_items, g.R), dim3(NT), WIN_CAP * sizeof(float) + TS * TS * 2 * sizeof(double), c->stream,
                                g, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta);
         }
         if (!identity) {
@@ -440,7 +442,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     eincm_ctx* c = new eincm_ctx();
     c->device = device; c->H = H; c->W = W; c->maxR = max_refs; c->maxB = max_windows; c->maxN = max_events_total;
     c->cflags = flags;
-    if (const char* s = getenv("EINCM_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= (1 << 20)) c->chunk = v; }
+    if (const char* s = getenv("EINCM_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= MAX_CHUNK) c->chunk = v; }
     auto bail = [&](const char* what, hipError_t err) -> eincm_ctx* {
         fail(nullptr, EINCM_ERR_HIP, "eincm_create: %s failed: %s", what, hipGetErrorString(err));
         free_all(c);

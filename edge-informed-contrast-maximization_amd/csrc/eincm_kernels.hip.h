@@ -28,6 +28,19 @@ constexpr int WIN_CAP = 9216;     // floats of LDS for an item's destination win
 constexpr int WIN_MAXW = 96;
 constexpr double EPSN = 2.220446049250313e-16;   // sys.float_info.epsilon (losses.py:24)
 constexpr float INV_2PI = 0.15915494309189535f;
+// LDS accumulation of the splat is u32 fixed point: on gfx950 ds_add_f32 retires ~1 lane per 3 clocks whatever the
+// address pattern (0.33 lane-ops/clk/CU measured, tools/lds_atomic_bench.hip) while ds_add_u32 sustains 5-7.4.
+// One tap is <= 1/(2*pi) = 0.1592 and an item holds <= MAX_CHUNK events, so a window pixel is < 4096*0.1592 = 652
+// < 2^32 / FIX_SCALE = 1024: the integer sum cannot overflow.  Resolution 2^-22 = 2.4e-7 (round to nearest, unbiased).
+constexpr int MAX_CHUNK = 4096;
+// Per-item scale 2^k, the largest power of two with count * 0.16 * 2^k <= 2^32 (k capped at 30, where the smallest
+// tap 0.0137 still keeps its full fp32 mantissa): k = 23 for 2048 events, 22 for 4096, 30 for <= 25 events — sparse
+// items are accumulated essentially exactly, dense ones with an absolute step (6e-8) below the fp32 ulp of their sums.
+__device__ __forceinline__ int fix_shift(int count) {
+    const unsigned c = (unsigned)ceilf((float)count * 0.16f);
+    const int ceillog2 = (c <= 1u) ? 0 : (32 - __clz(c - 1u));
+    return min(30, 32 - ceillog2);
+}
 constexpr float EXP_M05 = 0.6065306597126334f;   // exp(-1/2)
 
 struct Geom {
@@ -243,14 +256,16 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g,
         const double* __restrict__ edge_ts,    // (B,R)
         float* __restrict__ iwe)               // (B,R,H,W), zeroed
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t ldsu[];
     const Item it = items[blockIdx.x];
     const int r = blockIdx.y;
     const double tau = edge_ts[it.win * g.R + r];
     const Window wn = item_window(g, it, tmm + ((size_t)it.win * g.ntiles + it.tile) * 4, tau);
     const int nwin = wn.ww * wn.wh;
-    for (int i = threadIdx.x; i < nwin; i += NT) lds[i] = 0.0f;
+    for (int i = threadIdx.x; i < nwin; i += NT) ldsu[i] = 0u;
     __syncthreads();
+    const int fshift = fix_shift(it.count);
+    const float FIX_SCALE = ldexpf(1.0f, fshift), FIX_INV = ldexpf(1.0f, -fshift);
 
     float* __restrict__ img = iwe + ((size_t)it.win * g.R + r) * g.H * g.W;
     const double* __restrict__ Th = Theta + (size_t)it.win * g.H * g.W * 2;
@@ -268,14 +283,14 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g,
         float kx[3], ky[3];
         taps3(fx, kx[0], kx[1], kx[2]);
         taps3(fy, ky[0], ky[1], ky[2]);
-        ky[0] *= INV_2PI; ky[1] *= INV_2PI; ky[2] *= INV_2PI;
+        ky[0] *= INV_2PI * FIX_SCALE; ky[1] *= INV_2PI * FIX_SCALE; ky[2] *= INV_2PI * FIX_SCALE;
         const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;        // window coords of the top-left tap
         if (lx >= 0 && ly >= 0 && lx + 2 < wn.ww && ly + 2 < wn.wh) {
-            float* p = lds + ly * wn.ww + lx;
+            uint32_t* p = ldsu + ly * wn.ww + lx;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) atomicAdd(p + dy * wn.ww + dx, ky[dy] * kx[dx]);
+                for (int dx = 0; dx < 3; ++dx) atomicAdd(p + dy * wn.ww + dx, __float2uint_rn(ky[dy] * kx[dx]));
             }
         } else {
 #pragma unroll
@@ -285,10 +300,10 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g,
                     const int cx = lx + dx, cy = ly + dy;
                     const float k = ky[dy] * kx[dx];
                     if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
-                        atomicAdd(lds + cy * wn.ww + cx, k);
+                        atomicAdd(ldsu + cy * wn.ww + cx, __float2uint_rn(k));
                     } else {
                         const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
-                        if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, k);
+                        if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, k * FIX_INV);
                     }
                 }
             }
@@ -301,10 +316,10 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g,
         const int gy = wrap_drop(wn.oy + row, g.H);
         if (gy < 0) continue;
         for (int col = lane; col < wn.ww; col += 64) {
-            const float v = lds[row * wn.ww + col];
-            if (v != 0.0f) {
+            const uint32_t v = ldsu[row * wn.ww + col];
+            if (v != 0u) {
                 const int gx = wrap_drop(wn.ox + col, g.W);
-                if (gx >= 0) atomicAdd(img + (size_t)gy * g.W + gx, v);
+                if (gx >= 0) atomicAdd(img + (size_t)gy * g.W + gx, (float)v * FIX_INV);
             }
         }
     }
@@ -317,6 +332,9 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g,
 // T is an LDS tile accessor a(y, x) returning double.
 // ------------------------------------------------------------------------------------------------
 template <typename A> __device__ __forceinline__ void scharr_at(const A& a, int y, int x, double& gx, double& gy) {
+    // no FMA contraction: the TV term counts gradients that are EXACTLY zero (regularizers.py:26-29); with
+    // fma(3, a, round(3c)) the cancellation 3a + 3(-a) leaves the rounding error of 3a instead of 0.
+#pragma clang fp contract(off)
     const double ul = a(y - 1, x - 1), uc = a(y - 1, x), ur = a(y - 1, x + 1);
     const double ml = a(y, x - 1), mr = a(y, x + 1);
     const double dl = a(y + 1, x - 1), dc = a(y + 1, x), dr = a(y + 1, x + 1);
@@ -566,7 +584,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g,
         float* __restrict__ gTheta)            // (B,H,W,2), zeroed
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* accum = lds + WIN_CAP;              // TS*TS*2 floats
+    double* accum = reinterpret_cast<double*>(lds + WIN_CAP);   // TS*TS*2 doubles (ds_add_f64 is ~10x ds_add_f32 on gfx950)
     const Item it = items[blockIdx.x];
     const int r = blockIdx.y;
     const double tau = edge_ts[it.win * g.R + r];
@@ -580,7 +598,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g,
             lds[row * wn.ww + col] = (gx >= 0 && gy >= 0) ? Gi[(size_t)gy * g.W + gx] : 0.0f;
         }
     }
-    for (int i = threadIdx.x; i < TS * TS * 2; i += NT) accum[i] = 0.0f;
+    for (int i = threadIdx.x; i < TS * TS * 2; i += NT) accum[i] = 0.0;
     __syncthreads();
 
     const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
@@ -641,18 +659,17 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g,
             gwx += cs * kx[dx] * qx;
             gwy += csq * kx[dx];
         }
-        const float fdt = (float)dt;
-        float* a = accum + ((y - y0) * TS + (x - x0)) * 2;
-        atomicAdd(a, -fdt * gwx);
-        atomicAdd(a + 1, -fdt * gwy);
+        double* a = accum + ((y - y0) * TS + (x - x0)) * 2;
+        atomicAdd(a, -dt * (double)gwx);
+        atomicAdd(a + 1, -dt * (double)gwy);
     }
     __syncthreads();
     float* __restrict__ gT = gTheta + (size_t)it.win * g.H * g.W * 2;
     const int tw = min(TS, g.W - x0), th = min(TS, g.H - y0);
     for (int i = threadIdx.x; i < TS * TS * 2; i += NT) {
         const int c = i & 1, px = (i >> 1) % TS, py = (i >> 1) / TS;
-        const float v = accum[i];
-        if (px < tw && py < th && v != 0.0f) atomicAdd(gT + ((size_t)(y0 + py) * g.W + (x0 + px)) * 2 + c, v);
+        const double v = accum[i];
+        if (px < tw && py < th && v != 0.0) atomicAdd(gT + ((size_t)(y0 + py) * g.W + (x0 + px)) * 2 + c, (float)v);
     }
 }
 
