@@ -37,7 +37,9 @@ struct eincm_ctx {
     int H = 0, W = 0, maxR = 0, maxB = 0;
     int64_t maxN = 0;
     uint32_t cflags = 0;
-    int chunk = 2048;
+    int chunk = 2048;              // events per inner chunk of k_splat (u32 accumulation bound)
+    int seg = 0;                   // events per segment (0 = choose per batch); EINCM_SEG / EINCM_CHUNK override
+    int seg_used = 0;
     hipStream_t stream = nullptr;
     std::string err;
 
@@ -237,6 +239,9 @@ int ensure_resample(eincm_ctx* c, int h, int w, int method) {
     return EINCM_OK;
 }
 
+// blocks of the two event kernels: every (segment, reference time) pair, padded to a multiple of 8 segments (block_to_work)
+unsigned event_grid(const eincm_ctx* c) { return (unsigned)(((c->n_items + NXCD - 1) / NXCD) * NXCD * c->g.R); }
+
 // Launch the forward half: theta -> Theta -> IWE stack -> image statistics.
 // theta must already be in d_theta_in (identity: (B,H,W,2); else (B,h,w,2)).
 int launch_forward(eincm_ctx* c, int h, int w, bool identity) {
@@ -254,8 +259,8 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity) {
     {
         StageTimer t(c, EINCM_STAGE_SPLAT);
         if (c->n_items > 0)
-            hipLaunchKernelGGL(k_splat, dim3(c->n_items, g.R), dim3(NT), WIN_CAP * sizeof(float), c->stream, g, c->d_items,
-                           c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe);
+            hipLaunchKernelGGL(k_splat, dim3(event_grid(c)), dim3(NT), 2 * WIN_CAP * sizeof(float), c->stream, g, c->n_items,
+                               c->chunk, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe);
     }
     {
         StageTimer t(c, EINCM_STAGE_STATS);
@@ -340,8 +345,8 @@ int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_p
             StageTimer t(c, EINCM_STAGE_GATHER);
             HIPCHK(c, hipMemsetAsync(c->d_gTheta, 0, (size_t)g.B * img * 2 * sizeof(float), c->stream));
             if (c->n_items > 0)
-                hipLaunchKernelGGL(k_gather, dim3(c->n_items, g.R), dim3(NT), WIN_CAP * sizeof(float) + TS * TS * 2 * sizeof(double), c->stream,
-                               g, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta);
+                hipLaunchKernelGGL(k_gather, dim3(event_grid(c)), dim3(NT), WIN_CAP * sizeof(float) + TS * TS * 2 * sizeof(double), c->stream,
+                               g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta);
         }
         if (!identity) {
             StageTimer t(c, EINCM_STAGE_PROJECT);
@@ -443,6 +448,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     c->device = device; c->H = H; c->W = W; c->maxR = max_refs; c->maxB = max_windows; c->maxN = max_events_total;
     c->cflags = flags;
     if (const char* s = getenv("EINCM_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= MAX_CHUNK) c->chunk = v; }
+    if (const char* s = getenv("EINCM_SEG")) { int v = atoi(s); if (v >= 64 && v <= MAX_SEG) c->seg = v; }
     auto bail = [&](const char* what, hipError_t err) -> eincm_ctx* {
         fail(nullptr, EINCM_ERR_HIP, "eincm_create: %s failed: %s", what, hipGetErrorString(err));
         free_all(c);
@@ -454,7 +460,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const int tilesX = (W + TS - 1) / TS, tilesY = (H + TS - 1) / TS, ntiles = tilesX * tilesY;
     const size_t B = max_windows, R = max_refs, img = (size_t)H * W;
-    c->max_items = (int64_t)B * ntiles + max_events_total / c->chunk + 1;
+    c->max_items = (int64_t)B * ntiles + max_events_total / 256 + 1;   // segments are never shorter than 256 events unless a tile is
     c->coarse_cap = std::max<int64_t>(64 * 64 * 2, 2);   // coarse theta up to 64x64 (the pyramid tops out at 16x16)
     TRY(dalloc(&c->d_xy, (size_t)max_events_total));
     TRY(dalloc(&c->d_t, (size_t)max_events_total));
@@ -517,7 +523,15 @@ int eincm_set_windows(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_
     g.H = H; g.W = W; g.R = n_refs; g.B = n_windows;
     g.tilesX = (W + TS - 1) / TS; g.tilesY = (H + TS - 1) / TS; g.ntiles = g.tilesX * g.tilesY;
 
-    // ---- bin by (window, source tile), stable in the input (time) order; cut bins into work items ----
+    // Segment length: long enough that one window flush is amortised over many events, short enough that the two
+    // event kernels still launch >= ~2048 workgroups (8 per CU) when the batch is small.
+    int seg = c->seg;
+    if (seg <= 0) {
+        const int64_t per = (N * (int64_t)n_refs + 2047) / 2048;
+        seg = (int)std::min<int64_t>(16384, std::max<int64_t>(256, ((per + 255) / 256) * 256));
+    }
+    c->seg_used = seg;
+    // ---- bin by (window, source tile), stable in the input (time) order; cut bins into segments ----
     std::vector<uint32_t> sxy((size_t)std::max<int64_t>(N, 1));
     std::vector<double> st((size_t)std::max<int64_t>(N, 1));
     std::vector<Item> items;
@@ -543,10 +557,10 @@ int eincm_set_windows(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_
             st[d] = t[i];
         }
         for (int k = 0; k < g.ntiles; ++k) {
-            for (int64_t s = cnt[k]; s < cnt[k + 1]; s += c->chunk) {
+            for (int64_t s = cnt[k]; s < cnt[k + 1]; s += seg) {
                 Item it;
                 it.win = b; it.tile = k; it.begin = (int32_t)(base + s);
-                it.count = (int32_t)std::min<int64_t>(c->chunk, cnt[k + 1] - s);
+                it.count = (int32_t)std::min<int64_t>(seg, cnt[k + 1] - s);
                 double lo = st[it.begin], hi = st[it.begin];
                 for (int q = 1; q < it.count; ++q) { lo = std::min(lo, st[it.begin + q]); hi = std::max(hi, st[it.begin + q]); }
                 it.t_lo = lo; it.t_hi = hi;

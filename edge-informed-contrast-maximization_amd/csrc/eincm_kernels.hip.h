@@ -24,15 +24,17 @@ namespace eincm {
 constexpr int TS = 32;            // source tile edge (pixels)
 constexpr int NT = 256;           // threads per workgroup = 4 waves of 64
 constexpr int NWAVE = NT / 64;
-constexpr int WIN_CAP = 9216;     // floats of LDS for an item's destination window (36 KiB)
-constexpr int WIN_MAXW = 96;
+constexpr int WIN_CAP = 4608;     // pixels of LDS for a segment's destination window (u32 chunk + f32 sum = 36 KiB)
+constexpr int WIN_MAXW = 80;
+constexpr int NXCD = 8;           // XCDs: blocks b and b+8 share an L2 (round-robin dispatch; speed only, never correctness)
 constexpr double EPSN = 2.220446049250313e-16;   // sys.float_info.epsilon (losses.py:24)
 constexpr float INV_2PI = 0.15915494309189535f;
 // LDS accumulation of the splat is u32 fixed point: on gfx950 ds_add_f32 retires ~1 lane per 3 clocks whatever the
 // address pattern (0.33 lane-ops/clk/CU measured, tools/lds_atomic_bench.hip) while ds_add_u32 sustains 5-7.4.
 // One tap is <= 1/(2*pi) = 0.1592 and an item holds <= MAX_CHUNK events, so a window pixel is < 4096*0.1592 = 652
 // < 2^32 / FIX_SCALE = 1024: the integer sum cannot overflow.  Resolution 2^-22 = 2.4e-7 (round to nearest, unbiased).
-constexpr int MAX_CHUNK = 4096;
+constexpr int MAX_CHUNK = 4096;    // events per inner chunk (bounds the u32 sums)
+constexpr int MAX_SEG = 1 << 20;   // events per segment (one window flush per segment and reference time)
 // Per-item scale 2^k, the largest power of two with count * 0.16 * 2^k <= 2^32 (k capped at 30, where the smallest
 // tap 0.0137 still keeps its full fp32 mantissa): k = 23 for 2048 events, 22 for 4096, 30 for <= 25 events — sparse
 // items are accumulated essentially exactly, dense ones with an absolute step (6e-8) below the fp32 ulp of their sums.
@@ -48,7 +50,7 @@ struct Geom {
     int tilesX, tilesY, ntiles;
 };
 
-struct Item {                     // one unit of event work: <= chunk events of one source tile of one window
+struct Item {                     // one segment of event work: <= seg events of one source tile of one window
     int32_t win, tile, begin, count;
     double t_lo, t_hi;            // time range of its events
 };
@@ -163,21 +165,26 @@ __device__ __forceinline__ Window item_window(const Geom& g, const Item& it, con
 __device__ __forceinline__ void warp_axis(int x, double v, double dt, int& ir, float& f) {
     const double w = (double)x - v * dt;
     const double r = rint(w);
-    const double fr = w - r;
-    const bool ok = fabs(w) < 1.0e6;                 // |w| beyond any sensor: every tap is dropped
+    f = (float)(w - r);                              // garbage when !ok, but then every tap is dropped
+    const bool ok = fabs(w) < 1.0e6;                 // |w| beyond any sensor (or NaN): every tap is dropped
     ir = ok ? (int)r : -(1 << 24);
-    f = ok ? (float)fr : 0.0f;
 }
 
-// Separable 3-tap weights exp(-0.5*(d - f)^2), d = -1,0,1 (event_utils.py:52-56; the 1/(2*pi) is folded by the caller)
+// Separable 3-tap weights exp(-0.5*(d - f)^2), d = -1,0,1 (event_utils.py:52-56; the 1/(2*pi) is folded by the caller):
+//   exp(-0.5 (d-f)^2) = exp(-0.5 f^2) * exp(d f) * exp(-0.5 d^2).  Two v_exp_f32 + one v_rcp_f32 (1 ulp each).
 __device__ __forceinline__ void taps3(float f, float& wm, float& w0, float& wp) {
-    const float e0 = __expf(-0.5f * f * f);
-    const float ep = __expf(f);
-    const float em = __frcp_rn(ep);
-    wm = e0 * em * EXP_M05;     // d = -1: exp(-0.5 f^2 - f - 0.5)
+    constexpr float L2E = 1.4426950408889634f;
+    const float e0 = __builtin_amdgcn_exp2f(f * f * (-0.5f * L2E));
+    const float ep = __builtin_amdgcn_exp2f(f * L2E);
+    const float em = __builtin_amdgcn_rcpf(ep);
+    const float c = e0 * EXP_M05;
+    wm = c * em;                // d = -1: exp(-0.5 f^2 - f - 0.5)
     w0 = e0;
-    wp = e0 * ep * EXP_M05;     // d = +1
+    wp = c * ep;                // d = +1
 }
+
+// round-to-nearest fixed-point conversion of a positive value: fma + truncating convert (2 instructions)
+__device__ __forceinline__ uint32_t fix_u32(float a, float b) { return (uint32_t)fmaf(a, b, 0.5f); }
 
 // ------------------------------------------------------------------------------------------------
 // k_theta: Theta = A_H theta A_W^T per channel, and per-tile velocity bounds.
@@ -244,10 +251,23 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
     }
 }
 
+// Block -> (segment, reference time).  The R blocks that process one segment at the R reference times read the
+// same events; blocks b, b+8, b+16, ... are dealt to the same XCD back to back, so they are made siblings and
+// the 2nd..Rth read of a segment's events hits that XCD's L2 instead of HBM.  grid = ceil(n_items/8)*8*R.
+__device__ __forceinline__ bool block_to_work(int n_items, int R, int& item, int& r) {
+    const int b = blockIdx.x;
+    const int xcd = b % NXCD, slot = b / NXCD;
+    item = (slot / R) * NXCD + xcd;
+    r = slot % R;
+    return item < n_items;
+}
+
 // ------------------------------------------------------------------------------------------------
-// k_splat: the dominant kernel.  grid (n_items, R).
+// k_splat: the dominant kernel.  grid ceil(n_items/8)*8*R blocks (block_to_work), LDS 2*WIN_CAP*4 bytes.
+// A segment is walked in chunks of <= chunk events; each chunk is accumulated in u32 fixed point (exact integer
+// ds_add_u32) and committed into the segment's f32 window; the window is flushed to HBM once per segment.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_splat(Geom g,
+__global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk,
         const Item* __restrict__ items,
         const uint32_t* __restrict__ ev_xy,    // x | y << 16, binned by (window, tile)
         const double* __restrict__ ev_t,
@@ -257,69 +277,83 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g,
         float* __restrict__ iwe)               // (B,R,H,W), zeroed
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsu[];
-    const Item it = items[blockIdx.x];
-    const int r = blockIdx.y;
+    float* ldsf = reinterpret_cast<float*>(ldsu + WIN_CAP);
+    int item, r;
+    if (!block_to_work(n_items, g.R, item, r)) return;
+    const Item it = items[item];
     const double tau = edge_ts[it.win * g.R + r];
     const Window wn = item_window(g, it, tmm + ((size_t)it.win * g.ntiles + it.tile) * 4, tau);
     const int nwin = wn.ww * wn.wh;
-    for (int i = threadIdx.x; i < nwin; i += NT) ldsu[i] = 0u;
+    const bool multi = it.count > chunk;
+    for (int i = threadIdx.x; i < nwin; i += NT) { ldsu[i] = 0u; if (multi) ldsf[i] = 0.0f; }
     __syncthreads();
-    const int fshift = fix_shift(it.count);
-    const float FIX_SCALE = ldexpf(1.0f, fshift), FIX_INV = ldexpf(1.0f, -fshift);
 
     float* __restrict__ img = iwe + ((size_t)it.win * g.R + r) * g.H * g.W;
     const double* __restrict__ Th = Theta + (size_t)it.win * g.H * g.W * 2;
-    const uint32_t* __restrict__ exy = ev_xy + it.begin;
-    const double* __restrict__ et = ev_t + it.begin;
-
-    for (int i = threadIdx.x; i < it.count; i += NT) {
-        const uint32_t xy = exy[i];
-        const double dt = et[i] - tau;
-        const int x = xy & 0xffff, y = xy >> 16;
-        const double2 v = *reinterpret_cast<const double2*>(Th + ((size_t)y * g.W + x) * 2);
-        int irx, iry; float fx, fy;
-        warp_axis(x, v.x, dt, irx, fx);
-        warp_axis(y, v.y, dt, iry, fy);
-        float kx[3], ky[3];
-        taps3(fx, kx[0], kx[1], kx[2]);
-        taps3(fy, ky[0], ky[1], ky[2]);
-        ky[0] *= INV_2PI * FIX_SCALE; ky[1] *= INV_2PI * FIX_SCALE; ky[2] *= INV_2PI * FIX_SCALE;
-        const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;        // window coords of the top-left tap
-        if (lx >= 0 && ly >= 0 && lx + 2 < wn.ww && ly + 2 < wn.wh) {
-            uint32_t* p = ldsu + ly * wn.ww + lx;
+    float FIX_INV = 1.0f;
+    for (int c0 = 0; c0 < it.count; c0 += chunk) {
+        const int cnt = min(chunk, it.count - c0);
+        const int fshift = fix_shift(cnt);
+        const float FIX_SCALE = ldexpf(1.0f, fshift);
+        FIX_INV = ldexpf(1.0f, -fshift);
+        const uint32_t* __restrict__ exy = ev_xy + it.begin + c0;
+        const double* __restrict__ et = ev_t + it.begin + c0;
+        for (int i = threadIdx.x; i < cnt; i += NT) {
+            const uint32_t xy = exy[i];
+            const double dt = et[i] - tau;
+            const int x = xy & 0xffff, y = xy >> 16;
+            const double2 v = *reinterpret_cast<const double2*>(Th + ((size_t)y * g.W + x) * 2);
+            int irx, iry; float fx, fy;
+            warp_axis(x, v.x, dt, irx, fx);
+            warp_axis(y, v.y, dt, iry, fy);
+            float kx[3], ky[3];
+            taps3(fx, kx[0], kx[1], kx[2]);
+            taps3(fy, ky[0], ky[1], ky[2]);
+            ky[0] *= INV_2PI * FIX_SCALE; ky[1] *= INV_2PI * FIX_SCALE; ky[2] *= INV_2PI * FIX_SCALE;
+            const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;        // window coords of the top-left tap
+            if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
+                uint32_t* p = ldsu + ly * wn.ww + lx;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
+                for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) atomicAdd(p + dy * wn.ww + dx, __float2uint_rn(ky[dy] * kx[dx]));
-            }
-        } else {
+                    for (int dx = 0; dx < 3; ++dx) atomicAdd(p + dy * wn.ww + dx, fix_u32(ky[dy], kx[dx]));
+                }
+            } else {
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
+                for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int cx = lx + dx, cy = ly + dy;
-                    const float k = ky[dy] * kx[dx];
-                    if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
-                        atomicAdd(ldsu + cy * wn.ww + cx, __float2uint_rn(k));
-                    } else {
-                        const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
-                        if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, k * FIX_INV);
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int cx = lx + dx, cy = ly + dy;
+                        const float k = ky[dy] * kx[dx];
+                        if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
+                            atomicAdd(ldsu + cy * wn.ww + cx, fix_u32(ky[dy], kx[dx]));
+                        } else {
+                            const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
+                            if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, k * FIX_INV);
+                        }
                     }
                 }
             }
         }
+        __syncthreads();
+        if (multi) {                               // commit the chunk into the segment's f32 window
+            for (int i = threadIdx.x; i < nwin; i += NT) {
+                const uint32_t u = ldsu[i];
+                if (u != 0u) { ldsf[i] += (float)u * FIX_INV; ldsu[i] = 0u; }
+            }
+            __syncthreads();
+        }
     }
-    __syncthreads();
     // row-wise flush: a wave walks one window row -> contiguous fp32 atomics on one image row
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int row = wv; row < wn.wh; row += NWAVE) {
         const int gy = wrap_drop(wn.oy + row, g.H);
         if (gy < 0) continue;
         for (int col = lane; col < wn.ww; col += 64) {
-            const uint32_t v = ldsu[row * wn.ww + col];
-            if (v != 0u) {
+            const float v = multi ? ldsf[row * wn.ww + col] : (float)ldsu[row * wn.ww + col] * FIX_INV;
+            if (v != 0.0f) {
                 const int gx = wrap_drop(wn.ox + col, g.W);
-                if (gx >= 0) atomicAdd(img + (size_t)gy * g.W + gx, (float)v * FIX_INV);
+                if (gx >= 0) atomicAdd(img + (size_t)gy * g.W + gx, v);
             }
         }
     }
@@ -571,13 +605,13 @@ __global__ __launch_bounds__(NT) void k_div(Geom g, const float* __restrict__ iw
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_gather: reverse of the splat.  grid (n_items, R).  For every event of the item and this reference time:
+// k_gather: reverse of the splat.  grid as k_splat (block_to_work).  For every event of the segment and this reference time:
 //   dL/dwx = sum_taps G[p] * k * qx,  dL/dwy likewise (q = p - w; dropped taps contribute 0, wrapped taps read
 //   the wrapped pixel), then dL/dTheta[y,x,:] += -dt * (dL/dwx, dL/dwy)   (event_warpers.py:34-35).
 // The G window is staged in LDS with the same bounding box as the forward; per-pixel sums are accumulated in an
 // LDS copy of the source tile and flushed row-wise.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_gather(Geom g,
+__global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
         const double* __restrict__ Theta, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
         const float* __restrict__ G,           // (B,R,H,W)
@@ -585,8 +619,9 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g,
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     double* accum = reinterpret_cast<double*>(lds + WIN_CAP);   // TS*TS*2 doubles (ds_add_f64 is ~10x ds_add_f32 on gfx950)
-    const Item it = items[blockIdx.x];
-    const int r = blockIdx.y;
+    int item, r;
+    if (!block_to_work(n_items, g.R, item, r)) return;
+    const Item it = items[item];
     const double tau = edge_ts[it.win * g.R + r];
     const Window wn = item_window(g, it, tmm + ((size_t)it.win * g.ntiles + it.tile) * 4, tau);
     const float* __restrict__ Gi = G + ((size_t)it.win * g.R + r) * g.H * g.W;
@@ -620,7 +655,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g,
         ky[0] *= INV_2PI; ky[1] *= INV_2PI; ky[2] *= INV_2PI;
         float gv[3][3];
         const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;
-        if (lx >= 0 && ly >= 0 && lx + 2 < wn.ww && ly + 2 < wn.wh) {
+        if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
             const float* p = lds + ly * wn.ww + lx;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
