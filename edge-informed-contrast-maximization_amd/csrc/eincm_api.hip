@@ -447,7 +447,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     eincm_ctx* c = new eincm_ctx();
     c->device = device; c->H = H; c->W = W; c->maxR = max_refs; c->maxB = max_windows; c->maxN = max_events_total;
     c->cflags = flags;
-    if (const char* s = getenv("EINCM_CHUNK")) { int v = atoi(s); if (v >= 64 && v <= MAX_CHUNK) c->chunk = v; }
+    if (const char* s = getenv("EINCM_CHUNK")) { int v = atoi(s); if (v >= NT && v <= MAX_CHUNK) c->chunk = (v / NT) * NT; }
     if (const char* s = getenv("EINCM_SEG")) { int v = atoi(s); if (v >= 64 && v <= MAX_SEG) c->seg = v; }
     auto bail = [&](const char* what, hipError_t err) -> eincm_ctx* {
         fail(nullptr, EINCM_ERR_HIP, "eincm_create: %s failed: %s", what, hipGetErrorString(err));

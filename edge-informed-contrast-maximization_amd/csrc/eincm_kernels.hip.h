@@ -290,22 +290,36 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk,
 
     float* __restrict__ img = iwe + ((size_t)it.win * g.R + r) * g.H * g.W;
     const double* __restrict__ Th = Theta + (size_t)it.win * g.H * g.W * 2;
-    float FIX_INV = 1.0f;
-    for (int c0 = 0; c0 < it.count; c0 += chunk) {
-        const int cnt = min(chunk, it.count - c0);
-        const int fshift = fix_shift(cnt);
-        const float FIX_SCALE = ldexpf(1.0f, fshift);
-        FIX_INV = ldexpf(1.0f, -fshift);
-        const uint32_t* __restrict__ exy = ev_xy + it.begin + c0;
-        const double* __restrict__ et = ev_t + it.begin + c0;
-        for (int i = threadIdx.x; i < cnt; i += NT) {
-            const uint32_t xy = exy[i];
-            const double dt = et[i] - tau;
-            const int x = xy & 0xffff, y = xy >> 16;
-            const double2 v = *reinterpret_cast<const double2*>(Th + ((size_t)y * g.W + x) * 2);
+    const uint32_t* __restrict__ exy = ev_xy + it.begin;
+    const double* __restrict__ et = ev_t + it.begin;
+    const int n = it.count;
+    const int iters = (n + NT - 1) / NT;            // uniform over the workgroup
+    const int ipc = chunk / NT;                     // iterations per chunk (chunk is a multiple of NT)
+    int fshift = fix_shift(min(chunk, n));
+    float FIX_SCALE = ldexpf(1.0f, fshift), FIX_INV = ldexpf(1.0f, -fshift);
+
+    // Two-deep software pipeline: while event j is splatted, the Theta gather of event j+1 and the (xy, t) loads of
+    // event j+2 are in flight (the loop is otherwise bound by two dependent global-load latencies per event).
+    auto theta_at = [&](uint32_t xy) -> double2 {
+        return *reinterpret_cast<const double2*>(Th + ((size_t)(xy >> 16) * g.W + (xy & 0xffff)) * 2);
+    };
+    const int tid = threadIdx.x;
+    uint32_t xyA = (tid < n) ? exy[tid] : 0u;
+    double tA = (tid < n) ? et[tid] : 0.0;
+    uint32_t xyB = (tid + NT < n) ? exy[tid + NT] : 0u;
+    double tB = (tid + NT < n) ? et[tid + NT] : 0.0;
+    double2 vA = theta_at(xyA);
+    for (int j = 0; j < iters; ++j) {
+        const int e = j * NT + tid;
+        uint32_t xyC = 0u; double tC = 0.0;
+        if (e + 2 * NT < n) { xyC = exy[e + 2 * NT]; tC = et[e + 2 * NT]; }
+        const double2 vB = theta_at(xyB);           // xy = 0 (past the end) is pixel (0,0): a valid address
+        if (e < n) {
+            const double dt = tA - tau;
+            const int x = xyA & 0xffff, y = xyA >> 16;
             int irx, iry; float fx, fy;
-            warp_axis(x, v.x, dt, irx, fx);
-            warp_axis(y, v.y, dt, iry, fy);
+            warp_axis(x, vA.x, dt, irx, fx);
+            warp_axis(y, vA.y, dt, iry, fy);
             float kx[3], ky[3];
             taps3(fx, kx[0], kx[1], kx[2]);
             taps3(fy, ky[0], ky[1], ky[2]);
@@ -324,26 +338,29 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk,
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
                         const int cx = lx + dx, cy = ly + dy;
-                        const float k = ky[dy] * kx[dx];
                         if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
                             atomicAdd(ldsu + cy * wn.ww + cx, fix_u32(ky[dy], kx[dx]));
                         } else {
                             const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
-                            if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, k * FIX_INV);
+                            if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, ky[dy] * kx[dx] * FIX_INV);
                         }
                     }
                 }
             }
         }
-        __syncthreads();
-        if (multi) {                               // commit the chunk into the segment's f32 window
-            for (int i = threadIdx.x; i < nwin; i += NT) {
+        xyA = xyB; tA = tB; vA = vB; xyB = xyC; tB = tC;
+        if (multi && ((j + 1) % ipc == 0 || j + 1 == iters)) {     // chunk boundary (uniform): commit u32 -> f32 window
+            __syncthreads();
+            for (int i = tid; i < nwin; i += NT) {
                 const uint32_t u = ldsu[i];
                 if (u != 0u) { ldsf[i] += (float)u * FIX_INV; ldsu[i] = 0u; }
             }
             __syncthreads();
+            fshift = fix_shift(min(chunk, n - (j + 1) * NT));
+            FIX_SCALE = ldexpf(1.0f, fshift); FIX_INV = ldexpf(1.0f, -fshift);
         }
     }
+    if (!multi) __syncthreads();
     // row-wise flush: a wave walks one window row -> contiguous fp32 atomics on one image row
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int row = wv; row < wn.wh; row += NWAVE) {
@@ -641,11 +658,27 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     const double* __restrict__ Th = Theta + (size_t)it.win * g.H * g.W * 2;
     const uint32_t* __restrict__ exy = ev_xy + it.begin;
     const double* __restrict__ et = ev_t + it.begin;
-    for (int i = threadIdx.x; i < it.count; i += NT) {
-        const uint32_t xy = exy[i];
-        const double dt = et[i] - tau;
+    const int n = it.count;
+    const int iters = (n + NT - 1) / NT;
+    auto theta_at = [&](uint32_t xy) -> double2 {
+        return *reinterpret_cast<const double2*>(Th + ((size_t)(xy >> 16) * g.W + (xy & 0xffff)) * 2);
+    };
+    const int tid = threadIdx.x;
+    uint32_t xyA = (tid < n) ? exy[tid] : 0u;
+    double tA = (tid < n) ? et[tid] : 0.0;
+    uint32_t xyB = (tid + NT < n) ? exy[tid + NT] : 0u;
+    double tB = (tid + NT < n) ? et[tid + NT] : 0.0;
+    double2 vA = theta_at(xyA);
+    for (int j = 0; j < iters; ++j) {               // two-deep software pipeline, as in k_splat
+        const int e = j * NT + tid;
+        uint32_t xyC = 0u; double tC = 0.0;
+        if (e + 2 * NT < n) { xyC = exy[e + 2 * NT]; tC = et[e + 2 * NT]; }
+        const double2 vB = theta_at(xyB);
+        const uint32_t xy = xyA; const double tcur = tA; const double2 v = vA;
+        xyA = xyB; tA = tB; vA = vB; xyB = xyC; tB = tC;
+        if (e >= n) continue;
+        const double dt = tcur - tau;
         const int x = xy & 0xffff, y = xy >> 16;
-        const double2 v = *reinterpret_cast<const double2*>(Th + ((size_t)y * g.W + x) * 2);
         int irx, iry; float fx, fy;
         warp_axis(x, v.x, dt, irx, fx);
         warp_axis(y, v.y, dt, iry, fy);
