@@ -68,6 +68,8 @@ struct eincm_ctx {
     double* d_tmm = nullptr;       // (B,ntiles,4)
     StatPart* d_parts = nullptr;   // (B,R,ntiles)
     double* d_divparts = nullptr;  // (B,R,ntiles)
+    float* d_gdiv = nullptr;       // (B,R,H,W) divergence adjoint image, allocated on first delta != 0 gradient
+    double* d_dgparts = nullptr;   // (B,R,ntiles,2)
     double* d_tvparts = nullptr;   // (B,ntiles,3)
     WinConst* d_wc = nullptr;      // (B)
     OutScal* d_outs = nullptr;     // (B)
@@ -180,7 +182,7 @@ void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_edges); F(c->d_edge_ts); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
-    F(c->d_divparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); F(c->d_gth); F(c->d_grad); F(c->d_AH); F(c->d_AW);
+    F(c->d_divparts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); F(c->d_gth); F(c->d_grad); F(c->d_AH); F(c->d_AW);
     F(c->d_rowtap); F(c->d_coltap);
     auto FH = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
     FH(c->h_theta); FH(c->h_grad); FH(c->h_outs); FH(c->h_wc);
@@ -296,9 +298,11 @@ int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_p
     const size_t nth = (size_t)h * w * 2;
     const bool want_grad = (grad != nullptr);
     const bool full_aux = (p->flags & EINCM_PF_FULL_AUX) != 0;
-    if (p->delta != 0.0 && want_grad)
-        return fail(c, EINCM_ERR_UNSUPPORTED, "gradient of the IWE-divergence term (delta != 0) is not implemented; "
-                                               "the reference keeps delta = 0 (configs/main.yaml:19)");
+    const bool div_grad = (p->delta != 0.0 && want_grad);
+    if (div_grad && !c->d_gdiv) {      // rare path (the reference keeps delta = 0, configs/main.yaml:19): allocate lazily
+        HIPCHK(c, dalloc(&c->d_gdiv, (size_t)c->maxB * c->maxR * img));
+        HIPCHK(c, dalloc(&c->d_dgparts, (size_t)c->maxB * c->maxR * g.ntiles * 2));
+    }
     if (p->contrast_kind != EINCM_CONTRAST_GRAD_MAG && p->contrast_kind != EINCM_CONTRAST_VARIANCE)
         return fail(c, EINCM_ERR_ARG, "contrast_kind %d unknown", p->contrast_kind);
     if (!identity) {
@@ -338,8 +342,11 @@ int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_p
     if (want_grad) {
         {
             StageTimer t(c, EINCM_STAGE_IMGRAD);
+            if (div_grad)
+                hipLaunchKernelGGL(k_divgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_parts,
+                                   c->d_gdiv, c->d_dgparts);
             hipLaunchKernelGGL(k_imgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, ep, c->d_iwe, c->d_edges,
-                               c->d_parts, c->d_wc, c->d_G);
+                               c->d_parts, c->d_wc, c->d_gdiv, c->d_dgparts, c->d_G);
         }
         {
             StageTimer t(c, EINCM_STAGE_GATHER);

@@ -489,12 +489,14 @@ __device__ __forceinline__ double mse_from_moments(const ImgScal& s, double sE, 
 __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
         const float* __restrict__ iwe, const float* __restrict__ edges,
         const StatPart* __restrict__ parts, const WinConst* __restrict__ wc,
+        const float* __restrict__ gdiv, const double* __restrict__ dgparts,    // delta != 0 only (else unused)
         float* __restrict__ G)
 {
     constexpr int P2 = TS + 4, P1 = TS + 2;
     __shared__ float t[P2][P2 + 1];
     __shared__ double sgx[P1][P1 + 1], sgy[P1][P1 + 1];
-    __shared__ double sc[8];
+    __shared__ double sc[9];
+    const bool use_div = (ep.delta != 0.0);
     const int tile = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
@@ -506,6 +508,12 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
 
     if (threadIdx.x < 64) {
         const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.ntiles);
+        double dAn = 0.0, dA = 0.0;
+        if (use_div) {
+            const double* dp = dgparts + ((size_t)b * g.R + r) * g.ntiles * 2;
+            for (int i = threadIdx.x; i < g.ntiles; i += 64) { dAn += dp[2 * i]; dA += dp[2 * i + 1]; }
+            dAn = __shfl(wave_sum(dAn), 0, 64); dA = __shfl(wave_sum(dA), 0, 64);
+        }
         if (threadIdx.x == 0) {
             const double c0 = (ep.contrast_kind == 1) ? c.c0_var : c.c0_gradmag;
             const double a_r = -ep.alpha * c.mrw[r] / ((double)g.R * (c0 + EPSN));
@@ -515,8 +523,10 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
             const double S_En = s.sEI / s.D - a * c.sE[r];
             const double S_nn = s.sII / (s.D * s.D) - 2.0 * a * s.sI / s.D + HW * a * a;
             const double k = b_r * 2.0 / HW;
-            const double sGn_n = k * (S_En - S_nn);          // sum Gn*n
-            const double sGn = k * (c.sE[r] - S_n);          // sum Gn
+            const double e_hw = use_div ? ep.delta * c.mrw[r] / ((double)g.R * (c.d0 + EPSN) * HW) : 0.0;
+            const double sGn_n = k * (S_En - S_nn) + e_hw * dAn;     // sum Gn*n
+            const double sGn = k * (c.sE[r] - S_n) + e_hw * dA;      // sum Gn
+            sc[8] = e_hw / s.D;                              // scale on the divergence adjoint image
             sc[0] = s.m; sc[1] = s.M; sc[2] = s.D;
             sc[3] = a_r * 2.0 / HW;                          // contrast scale
             sc[4] = k / s.D;                                 // Gn/D scale on (E - n)
@@ -563,6 +573,7 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
         const double n = (v - m) / D;
         const double e = (double)E[(size_t)y * g.W + x];
         double gv = sc[3] * dc + sc[4] * (e - n);
+        if (use_div) gv += sc[8] * (double)gdiv[((size_t)b * g.R + r) * g.H * g.W + (size_t)y * g.W + x];
         if (v == m) gv += sc[5];
         if (v == M) gv += sc[6];
         Go[(size_t)y * g.W + x] = (float)gv;
@@ -619,6 +630,97 @@ __global__ __launch_bounds__(NT) void k_div(Geom g, const float* __restrict__ iw
     }
     sum = block_sum(sum, scratch);
     if (threadIdx.x == 0) divparts[((size_t)b * g.R + r) * g.ntiles + tile] = sum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_divgrad: reverse of k_div for delta != 0.  d = mean|div|, div = K (*) (n (*) Sx + n (*) Sy), every stage zero padded:
+//   A = d d / d n * HW = adj_Sx(t) + adj_Sy(t),  t = K (*) sign(div)  (K symmetric; sign(0) = 0; zero outside the image
+//   at every stage).  Writes the unscaled image A (fp32) and per-tile partials {sum A*n, sum A}; k_imgrad applies
+//   e_r/HW = delta*w_r/(R*(d0+eps)*HW) and folds the two sums into the min/max terms of the normalisation.
+// grid (ntiles, R, B).  Footprint: n on tile+4, gs on tile+3, sign on tile+2, t on tile+1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_divgrad(Geom g, const float* __restrict__ iwe, const StatPart* __restrict__ parts,
+                                                 float* __restrict__ gdiv, double* __restrict__ dgparts)
+{
+    constexpr int P4 = TS + 8, P3 = TS + 6, P2 = TS + 4, P1 = TS + 2;
+    __shared__ double nn[P4][P4 + 1];
+    __shared__ double gs[P3][P3 + 1];
+    __shared__ float sg[P2][P2 + 1];
+    __shared__ double tt[P1][P1 + 1];
+    __shared__ double sc[2];
+    __shared__ double scratch[NWAVE];
+    const int tile = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
+    const int tx = tile % g.tilesX, ty = tile / g.tilesX;
+    const int x0 = tx * TS, y0 = ty * TS;
+    const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
+    if (threadIdx.x < 64) {
+        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.ntiles);
+        if (threadIdx.x == 0) { sc[0] = s.m; sc[1] = s.D; }
+    }
+    __syncthreads();
+    const double m = sc[0], D = sc[1];
+    auto inimg = [&](int y, int x) -> bool { return y >= 0 && y < g.H && x >= 0 && x < g.W; };
+    for (int p = threadIdx.x; p < P4 * P4; p += NT) {
+        const int ly = p / P4, lx = p % P4;
+        const int y = y0 + ly - 4, x = x0 + lx - 4;
+        nn[ly][lx] = inimg(y, x) ? ((double)I[(size_t)y * g.W + x] - m) / D : 0.0;
+    }
+    __syncthreads();
+    auto acc = [&](int y, int x) -> double { return nn[y][x]; };
+    for (int p = threadIdx.x; p < P3 * P3; p += NT) {
+        const int ly = p / P3, lx = p % P3;
+        double gx = 0.0, gy = 0.0;
+        if (inimg(y0 + ly - 3, x0 + lx - 3)) scharr_at(acc, ly + 1, lx + 1, gx, gy);
+        gs[ly][lx] = gx + gy;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P2 * P2; p += NT) {
+        const int ly = p / P2, lx = p % P2;
+        float sgn = 0.0f;
+        if (inimg(y0 + ly - 2, x0 + lx - 2)) {
+            const int cy = ly + 1, cx = lx + 1;
+            const double d = (1.0 / 12.0) * (gs[cy - 1][cx - 1] + gs[cy - 1][cx + 1] + gs[cy + 1][cx - 1] + gs[cy + 1][cx + 1])
+                           + (1.0 / 6.0) * (gs[cy - 1][cx] + gs[cy + 1][cx] + gs[cy][cx - 1] + gs[cy][cx + 1]);
+            sgn = (d > 0.0) ? 1.0f : ((d < 0.0) ? -1.0f : 0.0f);
+        }
+        sg[ly][lx] = sgn;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P1 * P1; p += NT) {
+        const int ly = p / P1, lx = p % P1;
+        double t = 0.0;
+        if (inimg(y0 + ly - 1, x0 + lx - 1)) {
+            const int cy = ly + 1, cx = lx + 1;
+            t = (1.0 / 12.0) * ((double)sg[cy - 1][cx - 1] + sg[cy - 1][cx + 1] + sg[cy + 1][cx - 1] + sg[cy + 1][cx + 1])
+              + (1.0 / 6.0) * ((double)sg[cy - 1][cx] + sg[cy + 1][cx] + sg[cy][cx - 1] + sg[cy][cx + 1]);
+        }
+        tt[ly][lx] = t;
+    }
+    __syncthreads();
+    float* __restrict__ out = gdiv + ((size_t)b * g.R + r) * g.H * g.W;
+    double sAn = 0.0, sA = 0.0;
+    for (int p = threadIdx.x; p < TS * TS; p += NT) {
+        const int ly = p / TS, lx = p % TS;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= g.H || x >= g.W) continue;
+        const int cy = ly + 1, cx = lx + 1;
+        // adj_Sx(t) + adj_Sy(t) = -(conv(t,Sx) + conv(t,Sy))
+        const double ax = 3.0 * (tt[cy + 1][cx + 1] - tt[cy + 1][cx - 1]) + 10.0 * (tt[cy][cx + 1] - tt[cy][cx - 1])
+                        + 3.0 * (tt[cy - 1][cx + 1] - tt[cy - 1][cx - 1]);
+        const double ay = 3.0 * (tt[cy + 1][cx + 1] - tt[cy - 1][cx + 1]) + 10.0 * (tt[cy + 1][cx] - tt[cy - 1][cx])
+                        + 3.0 * (tt[cy + 1][cx - 1] - tt[cy - 1][cx - 1]);
+        const double A = -(ax + ay);
+        out[(size_t)y * g.W + x] = (float)A;
+        const double Af = (double)(float)A;              // what k_imgrad will read back
+        sAn += Af * nn[ly + 4][lx + 4];
+        sA += Af;
+    }
+    sAn = block_sum(sAn, scratch);
+    sA = block_sum(sA, scratch);
+    if (threadIdx.x == 0) {
+        double* o = dgparts + (((size_t)b * g.R + r) * g.ntiles + tile) * 2;
+        o[0] = sAn; o[1] = sA;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

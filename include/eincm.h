@@ -30,7 +30,7 @@ extern "C" {
 #define EINCM_ERR_HIP         -2   /* HIP runtime error (message holds hipGetErrorString) */
 #define EINCM_ERR_STATE       -3   /* call out of order (e.g. loss_grad before set_windows) */
 #define EINCM_ERR_NONFINITE   -4   /* loss or gradient is NaN/Inf (outputs are still written) */
-#define EINCM_ERR_UNSUPPORTED -5   /* valid request this build does not implement */
+#define EINCM_ERR_UNSUPPORTED -5   /* valid request this build does not implement (currently unused) */
 
 /* contrast objective: 0 = mean squared Scharr gradient magnitude of the raw IWE (losses.py:70, the reference's
  * live objective); 1 = variance of the IWE (contrast_objectives.py:29-39; BASELINE config "variance-only") */
