@@ -1,0 +1,183 @@
+"""Host logic around the path, exercised on CPU with the oracle standing in for the engine:
+the jaxopt-shaped SciPy wrappers, the multi-level solver, the maxiter schedule, window staging, the YAML reader."""
+import importlib
+import os
+from functools import partial
+
+import numpy as np
+import pytest
+
+from oracle import eincm_oracle as O
+
+sol = importlib.import_module('edge-informed-contrast-maximization_amd.solver')
+staging = importlib.import_module('edge-informed-contrast-maximization_amd.staging')
+config = importlib.import_module('edge-informed-contrast-maximization_amd.config')
+evaluation = importlib.import_module('edge-informed-contrast-maximization_amd.evaluation')
+synth = importlib.import_module('edge-informed-contrast-maximization_amd.synth')
+
+
+def test_growing_maxiter_schedule():
+    """Defaults of configs/main.yaml:35-50 -> levels 0..4 = 40,28,19,11,8 (BFGS) and 20,14,10,6,4 (L-BFGS-B) (SURVEY C.4 iv)."""
+    assert list(sol.growing_maxiters(5, 8, 40).values()) == [40, 28, 19, 11, 8]
+    assert list(sol.growing_maxiters(5, 4, 20).values()) == [20, 14, 10, 6, 4]
+    assert list(sol.growing_maxiters(5, 8, 40, use_growing=False).values()) == [40] * 5
+
+
+def test_scipy_minimize_wrapper_shape():
+    target = np.arange(8.0).reshape(2, 2, 2)
+    seen = []
+
+    def fun(x, scale):
+        d = x - target
+        return (float(scale * (d * d).sum()), {'aux': 1}), 2 * scale * d
+
+    s = sol.ScipyMinimize(fun=fun, method='BFGS', maxiter=50, jit=True, has_aux=True, options={'gtol': 1e-9, 'return_all': True},
+                          callback=lambda ir: seen.append((ir.x.shape, float(ir.fun))))
+    params, state = s.run(np.zeros((2, 2, 2)), 3.0)
+    assert params.shape == (2, 2, 2) and np.allclose(params, target, atol=1e-6)
+    assert state.success and state.status == 0 and state.iter_num > 0 and state.fun_val < 1e-10
+    assert seen and seen[0][0] == (2, 2, 2) and seen[-1][1] < seen[0][1]
+    b = sol.ScipyBoundedMinimize(fun=lambda a, c: (float((a[0] - c) ** 2), np.array([2 * (a[0] - c)])), method='L-BFGS-B',
+                                 maxiter=50, has_aux=False, options={'gtol': 1e-10})
+    a, st = b.run(np.array([0.5]), (0.0, 1.0), 3.0)       # unconstrained optimum 3 -> clipped to the bound
+    assert a[0] == pytest.approx(1.0) and st.iter_num >= 1
+
+
+def _oracle_pfuncs(H, W, alpha=20.0, beta=35.0, gamma=0.0):
+    def vg(theta, xs, ys, ts, edges, edge_ts, cur_pyr_lvl):
+        v, g, aux = O.loss_and_grad(theta, xs, ys, ts, edges, edge_ts, alpha, beta, gamma, 0.0, cur_pyr_lvl, 5, (H, W))
+        return (v, aux), g
+
+    def ho(a, prev, theta, xs, ys, ts, edges, edge_ts, cur_pyr_lvl):
+        return O.handover_loss_and_grad(float(np.asarray(a).reshape(-1)[0]), prev, theta, xs, ys, ts, edges, edge_ts,
+                                        alpha=alpha, beta=beta, gamma=gamma, delta=0.0, cur_pyr_lvl=cur_pyr_lvl, n_pyr_lvls=5,
+                                        sensor_size=(H, W))
+    return vg, ho
+
+
+def test_multi_level_solver_two_windows():
+    H, W, n_lvls = 32, 40, 3
+    vg, ho = _oracle_pfuncs(H, W)
+    cb = sol.CollectingCallback()
+    s = sol.MultipleLevelEINCMSolver(
+        n_pyr_lvls=n_lvls, theta_opt_maxiters=sol.growing_maxiters(n_lvls, 2, 6), theta_loss_pfunc=vg,
+        theta_opt_solver_params={'method': 'BFGS', 'options': {'gtol': 1e-7}, 'n_extra_attempts': {'pyr_lvl_0': 1}},
+        handover_opt_maxiters=sol.growing_maxiters(n_lvls, 2, 4), handover_loss_pfunc=ho,
+        handover_opt_solver_params={'method': 'L-BFGS-B', 'options': {'gtol': 1e-6}},
+        handover_settings={'use_handover': True, 'solve_handover_for_levels': [1, 0], 'use_downscaled_finest_priors': True,
+                           'handover_limits': [0.0, 1.0], 'clip_solved_handover': False, 'alpha_handover': 0.67},
+        pyramid_downscale_method='lanczos3', pyramid_upscale_method='repeat', pyramid_bases=[2, 2], theta_solver_callback=cb)
+    assert [s.pre_opt_theta_pyr[f'pyr_lvl_{k}'].shape for k in range(n_lvls)] == [(4, 4, 2), (2, 2, 2), (1, 1, 2)]
+    win = synth.make_window(1, (H, W), 1500, 2, flow='constant', flow_mag=4.0)
+    args = (win['xs'], win['ys'], win['ts'], win['edges'], win['edge_ts'])
+    s.set_datasample(*args)
+    out = s.solve()
+    assert set(out) == {'prior_theta_pyr', 'pre_opt_theta_pyr', 'theta_opt_state_pyr', 'pre_handover_theta_pyr', 'ho_opt_state_pyr',
+                        'final_handover_weight_pyr', 'final_theta_pyr'}            # solver.py:258-267
+    assert out['ho_opt_state_pyr'] == {}                                              # first window: no handover (solver.py:305-306)
+    for k in range(n_lvls):
+        np.testing.assert_array_equal(out['final_theta_pyr'][f'pyr_lvl_{k}'], out['pre_handover_theta_pyr'][f'pyr_lvl_{k}'])
+    v0 = vg(np.zeros((1, 1, 2)), *args, cur_pyr_lvl=2)[0][0]
+    assert out['theta_opt_state_pyr']['pyr_lvl_2'].fun_val < v0                       # the coarse level improved on theta = 0
+    assert cb.get_iters()['pyr_lvl_2'] >= 1 and cb.thetas['pyr_lvl_2'][0].shape == (1, 1, 2)
+    # second window: priors are the first window's finals, down-scaled with lanczos3; handover solved at levels 1 and 0
+    first_final = out['final_theta_pyr']['pyr_lvl_0']
+    win2 = synth.make_window(2, (H, W), 1500, 2, flow='constant', flow_mag=4.0)
+    s.set_datasample(win2['xs'], win2['ys'], win2['ts'], win2['edges'], win2['edge_ts'])
+    out2 = s.solve()
+    np.testing.assert_array_equal(out2['prior_theta_pyr']['pyr_lvl_0'], first_final)
+    np.testing.assert_allclose(out2['prior_theta_pyr']['pyr_lvl_1'], sol.rescale_theta(first_final, (2, 2), 'lanczos3'))
+    assert set(out2['ho_opt_state_pyr']) == {'pyr_lvl_1', 'pyr_lvl_0'}
+    assert out2['final_handover_weight_pyr']['pyr_lvl_2'] == 0.67                    # fixed weight where not solved
+    for k in (0, 1):
+        a = out2['final_handover_weight_pyr'][f'pyr_lvl_{k}']
+        assert 0.0 <= a <= 1.0
+        key = f'pyr_lvl_{k}'
+        np.testing.assert_allclose(out2['final_theta_pyr'][key],
+                                   a * out2['prior_theta_pyr'][key] + (1 - a) * out2['pre_handover_theta_pyr'][key])
+
+
+def test_rescale_theta_matches_oracle_resampling():
+    th = np.random.default_rng(0).normal(size=(4, 4, 2))
+    up = sol.rescale_theta(th, (8, 8), 'bilinear')
+    A = O.resample_matrix(4, 8, 2.0, 'bilinear')
+    np.testing.assert_allclose(up, np.einsum('yi,xj,ijc->yxc', A, A, th), rtol=1e-14)
+    dn = sol.rescale_theta(th, (2, 2), 'lanczos3')
+    A = O.resample_matrix(4, 2, 0.5, 'lanczos3')
+    C = O.resample_matrix(2, 2, 1.0, 'lanczos3')
+    np.testing.assert_allclose(dn, np.einsum('yi,xj,dc,ijc->yxd', A, A, C, th), rtol=1e-14)
+
+
+def test_fit_event_window_rules():
+    # short window grows symmetrically (ceil before, floor after), clamped to the stream  (mvsec_loader.py:278-283)
+    assert staging.fit_event_window(1000, 400, 500, 205) == (347, 552, 105)
+    assert staging.fit_event_window(1000, 10, 60, 200) == (0, 135, 150)
+    assert staging.fit_event_window(1000, 950, 990, 200)[:2] == (870, 1000)
+    # long window keeps the latest / earliest des_n_events  (mvsec_loader.py:288-291)
+    assert staging.fit_event_window(1000, 100, 700, 200, True) == (500, 700, -400)
+    assert staging.fit_event_window(1000, 100, 700, 200, False) == (100, 300, -400)
+    t = np.arange(100.0)
+    sl, d = staging.select_events(t, 20.0, 29.0, des_n_events=10)
+    assert (sl.start, sl.stop, d) == (20, 30, 0)
+
+
+def test_time_normalisation_and_stage():
+    ts = np.array([1000.0, 1500.0, 2000.0])
+    tn, im = staging.normalize_times(ts, np.array([1000, 2000]), 1000.0, 2000.0)
+    assert tn[0] == 0.0 and tn[1] == pytest.approx(0.5) and tn[2] == pytest.approx(1.0) and tn[2] < 1.0 + 1e-12
+    ds = {'events': {'x': np.array([1, 2, 3]), 'y': np.array([4, 5, 6]), 't': ts, 'p': np.array([1, 0, 1])},
+          'image_ts': np.array([1000.0, 2000.0]), 'eval_ts': (1000.0, 2000.0)}
+    xs, ys, t, edges, ets = staging.stage_datasample(ds, [np.array([[0.0, 2.0], [4.0, 1.0]]), np.ones((2, 2))])
+    assert xs.dtype == np.int16 and ys.dtype == np.int16 and t.dtype == np.float64
+    assert edges.shape == (2, 2, 2) and edges[0].min() == 0.0 and edges[0].max() == pytest.approx(1.0) and np.all(edges[1] == 0.0)
+    np.testing.assert_allclose(ets, [0.0, 1.0])
+
+
+def test_yaml_config_reader(tmp_path):
+    """Same constructs as src/experiments/e00/configs: defaults groups, ${a.b} interpolation, nested ${..${..}}, divide."""
+    (tmp_path / 'dataset').mkdir()
+    (tmp_path / 'theta_loss_func').mkdir()
+    (tmp_path / 'main.yaml').write_text(
+        'defaults:\n  - _self_\n  - dataset: dsec\n  - theta_loss_func: default\n'
+        'alpha: 20\nbeta: 35\nsequence_name: seq_b\nn_pyr_lvls: 5\n'
+        'solver_params:\n  theta_opt:\n    maxiter: 40\n    miniter: ${divide:${solver_params.theta_opt.maxiter},5}\n'
+        '    options:\n      gtol: 1e-7\n')
+    (tmp_path / 'dataset' / 'dsec.yaml').write_text(
+        'height: 480\nwidth: 640\nsensor_size:\n  - ${dataset.height}\n  - ${dataset.width}\n'
+        'split:\n  seq_a: train\n  seq_b: test\nloader:\n  data_split: ${dataset.split.${sequence_name}}\n')
+    (tmp_path / 'dataset' / 'mvsec.yaml').write_text('height: 256\nwidth: 336\nsensor_size:\n  - ${dataset.height}\n  - ${dataset.width}\n')
+    (tmp_path / 'theta_loss_func' / 'default.yaml').write_text(
+        '_partial_: true\n_target_: eincm.losses.loss_func\nalpha: ${alpha}\nsensor_size: ${dataset.sensor_size}\n')
+    cfg = config.load_config(str(tmp_path), 'main')
+    assert cfg.dataset.sensor_size == [480, 640] and cfg.theta_loss_func.sensor_size == [480, 640]
+    assert cfg.solver_params.theta_opt.miniter == 8.0 and cfg.solver_params.theta_opt.options.gtol == 1e-7
+    assert cfg.dataset.loader.data_split == 'test' and cfg.theta_loss_func.alpha == 20
+    cfg = config.load_config(str(tmp_path), 'main', ['dataset=mvsec', 'alpha=60', 'solver_params.theta_opt.maxiter=50'])
+    assert cfg.dataset.sensor_size == [256, 336] and cfg.theta_loss_func.alpha == 60 and cfg.solver_params.theta_opt.miniter == 10.0
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/src/experiments/e00/configs'), reason='reference tree not present')
+def test_yaml_reader_on_the_reference_tree():
+    cfg = config.load_config('/root/reference/src/experiments/e00/configs', 'main', ['dataset=mvsec'])
+    assert cfg.dataset.sensor_size == [256, 336] and (cfg.alpha, cfg.beta, cfg.gamma, cfg.delta) == (20, 35, 0.00025, 0.0)
+    assert cfg.theta_loss_func._target_ == 'eincm.losses.loss_func' and cfg.theta_loss_func.scale_to_sensor_size_method == 'bilinear'
+    assert cfg.solver_params.theta_opt.miniter == 8.0 and cfg.handover_settings.solve_handover_for_levels == [1, 0]
+    mi = sol.growing_maxiters(cfg.n_pyr_lvls, cfg.solver_params.theta_opt.miniter, cfg.solver_params.theta_opt.maxiter,
+                              cfg.maxiters_grow_order, cfg.use_growing_maxiters)
+    assert list(mi.values()) == [40, 28, 19, 11, 8]
+
+
+def test_sparse_flow_error():
+    H, W = 6, 8
+    gt = np.zeros((H, W, 2)); gt[1:5, 1:7] = (3.0, 4.0); gt[2, 2] = (np.inf, 0.0)
+    pred = gt.copy(); pred[~np.isfinite(pred)] = 1.0
+    pred[1, 1] = (3.0, 4.0 + 2.5)            # error 2.5
+    pred[1, 2] = (0.0, 0.0)                  # zero prediction: not evaluated
+    mask = np.zeros((H, W), bool); mask[1:5, 1:7] = True; mask[4, 6] = False
+    r = evaluation.sparse_flow_error(pred, gt, mask)
+    n = 4 * 6 - 1 - 1 - 1                    # inf gt, zero pred, masked-out pixel
+    assert r['counts']['n_ee'] == n and r['counts']['n_gt'] == 23
+    assert r['errors']['AEE'] == pytest.approx(2.5 / n) and r['errors']['AREE'] == pytest.approx(0.5 / n)
+    assert r['errors']['A1PE'] == pytest.approx(100.0 / n) and r['errors']['A3PE'] == 0.0
+    flow = evaluation.per_pix_theta_to_flow(np.ones((H, W, 2)), np.array([1, 3]), np.array([2, 2]))
+    assert flow.sum() == 4.0 and flow[2, 1, 0] == 1.0 and flow[2, 3, 1] == 1.0
