@@ -171,21 +171,32 @@ def main():
         out['eval_ms_single_window'] = float(np.median(ts) * 1e3)
         out['warped_events_per_s_single_window'] = N * R / float(np.median(ts))
 
-    # ---- CPU baseline: the fp64 numpy oracle (a port of the reference arithmetic; the reference itself cannot run) ----
+    # ---- CPU baseline: ports of the reference arithmetic (the reference itself, JAX, cannot run here or on the GPU box) ----
+    # Reported: the C / OpenMP port (oracle/eincm_ref.c) on the host cores of this box; the single-core numpy oracle beside it.
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import eincm_oracle as O
+        from oracle import eincm_c_port as CP
         wn = wins[0]
+        cargs = (wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts'])
+        cores = max(1, min(16, os.cpu_count() or 1, CP.max_threads()))      # a 1-GPU box's CPU share is 16 threads
+        CP.loss_and_grad(theta_at(0)[0], *cargs, alpha, beta, (H, W), nthreads=cores)      # warm (page-in, thread pool)
         n_eval, t_cpu = 0, 0.0
-        while t_cpu < 10.0 and n_eval < 8:
+        while t_cpu < 8.0 and n_eval < 64:
             t0 = time.perf_counter()
-            O.loss_and_grad(theta_at(n_eval)[0], wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts'], alpha, beta, 0.0, 0.0,
-                            4 if not dense else 0, 5, (H, W))
+            CP.loss_and_grad(theta_at(n_eval)[0], *cargs, alpha, beta, (H, W), nthreads=cores)
             t_cpu += time.perf_counter() - t0
             n_eval += 1
-        out['cpu_baseline'] = {'value': n_eval * N * R / t_cpu, 'unit': 'warped-events/s', 'cores': 1, 'kind': 'port',
-                               'sample': f'{n_eval} loss+grad evaluations of 1 window ({H}x{W}, N={N}, R={R}) by the numpy fp64 '
-                                         f'oracle, {t_cpu:.1f} s', 'eval_ms': t_cpu / n_eval * 1e3,
-                               'host_cores_available': os.cpu_count()}
+        n_np, t_np = 0, 0.0
+        while t_np < 4.0 and n_np < 4:
+            t0 = time.perf_counter()
+            O.loss_and_grad(theta_at(n_np)[0], *cargs, alpha, beta, 0.0, 0.0, 4 if not dense else 0, 5, (H, W))
+            t_np += time.perf_counter() - t0
+            n_np += 1
+        out['cpu_baseline'] = {'value': n_eval * N * R / t_cpu, 'unit': 'warped-events/s', 'cores': cores, 'kind': 'port',
+                               'sample': f'{n_eval} loss+grad evaluations of 1 window ({H}x{W}, N={N}, R={R}) by the C/OpenMP fp64 port '
+                                         f'(oracle/eincm_ref.c, {cores} threads), {t_cpu:.1f} s; numpy oracle on 1 core: {n_np} evaluations, {t_np:.1f} s',
+                               'eval_ms': t_cpu / n_eval * 1e3, 'numpy_1core_value': n_np * N * R / t_np,
+                               'numpy_1core_eval_ms': t_np / n_np * 1e3, 'host_cores_available': os.cpu_count()}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
