@@ -84,7 +84,7 @@ def main():
     else:
         base = np.stack([synth.theta_near_truth(1000 * rank + b, wn, (h, w)) for b, wn in enumerate(wins)])
     n_theta = a.steps + a.warmup
-    eng = engine.Engine((H, W), B * N, max_refs=R, max_windows=B, device=local_rank, timing=True)
+    eng = engine.Engine((H, W), B * N, max_refs=R, max_windows=B, device=local_rank, timing='dominant')
     t0 = time.perf_counter()
     eng.set_windows([(wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts']) for wn in wins])
     t_stage = time.perf_counter() - t0
@@ -123,10 +123,22 @@ def main():
     warped = world * B * N * R           # warped events per step, all ranks
     value = warped / (elapsed / a.steps)
 
+    # per-stage device times: a separate, untimed diagnostic pass (bracketing every kernel costs ~10 % of a step)
+    diag = {}
+    if rank == 0:
+        eng.close()
+        eng = engine.Engine((H, W), B * N, max_refs=R, max_windows=B, device=local_rank, timing=True)
+        eng.set_windows([(wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts']) for wn in wins])
+        nd = min(5, a.steps)
+        for k in range(2 + nd):
+            eng.loss_grad(theta_at(k), p)
+            if k >= 2:
+                for kk, vv in eng.timings().items():
+                    diag[kk] = diag.get(kk, 0.0) + vv / nd
+
     out = None
     if rank == 0:
         splat_ms = stage_acc.get('splat', 0.0) / a.steps
-        gather_ms = stage_acc.get('gather', 0.0) / a.steps
         splat_bytes = B * splat_algorithmic_bytes(N, R, H, W)
         achieved = splat_bytes / (splat_ms * 1e-3) / 1e9 if splat_ms > 0 else 0.0
         traffic = None
@@ -148,11 +160,17 @@ def main():
                        'theta': [h, w, 2], 'parallelism': f'window-parallel x{world}, scalar-loss all-reduce'},
             'roofline': {'bound': 'hbm', 'kernel': 'k_splat', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': splat_bytes, 'avg_launch_ms': splat_ms},
+                         'algorithmic_bytes_per_launch': splat_bytes, 'avg_launch_ms': splat_ms,
+                         'binding_resource': 'lds_atomic',
+                         'lds_atomic_lane_ops_per_clk_per_cu': (9.0 * B * N * R / (splat_ms * 1e-3) / 256 / 2.4e9) if splat_ms > 0 else 0.0,
+                         'lds_atomic_peak_lane_ops_per_clk_per_cu': [4.8, 7.4],
+                         'lds_atomic_note': '9 ds_add_u32 per warped event; peak = tools/lds_atomic_bench.hip (clustered, distinct addresses), profiles/r01/lds_atomic_microbench.txt'},
             'eval_roofline': {'achieved': eval_bytes / (ms_per_step * 1e-3) / 1e9, 'unit': 'GB/s',
                               'frac': eval_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                               'algorithmic_bytes_per_step': eval_bytes},
-            'stage_ms_per_step': {k: round(vv / a.steps, 4) for k, vv in stage_acc.items()},
+            'device_ms_per_step': round(stage_acc.get('total', 0.0) / a.steps, 4),
+            'stage_ms_per_step': {k: round(vv, 4) for k, vv in diag.items()},
+            'stage_ms_note': 'separate diagnostic pass with every kernel bracketed by HIP events (slower than the timed region)',
             'set_windows_s': t_stage,
             'warped_events_per_s_per_gpu': value / world,
         }

@@ -14,6 +14,7 @@ CONTRAST_GRAD_MAG, CONTRAST_VARIANCE = 0, 1
 METHODS = {'linear': 0, 'bilinear': 0, 'triangle': 0, 'lanczos3': 1, 'lanczos5': 2, 'cubic': 3, 'bicubic': 3}
 PF_FULL_AUX = 1
 CF_TIMING = 1
+CF_TIMING_DOMINANT = 2
 
 
 class Params(C.Structure):

@@ -195,7 +195,8 @@ void free_all(eincm_ctx* c) {
 
 struct StageTimer {
     eincm_ctx* c; int stage; bool on;
-    StageTimer(eincm_ctx* c_, int s) : c(c_), stage(s), on((c_->cflags & EINCM_CF_TIMING) != 0) {
+    StageTimer(eincm_ctx* c_, int s) : c(c_), stage(s),
+        on((c_->cflags & EINCM_CF_TIMING) != 0 || ((c_->cflags & EINCM_CF_TIMING_DOMINANT) != 0 && s == EINCM_STAGE_SPLAT)) {
         if (on) { (void)hipEventRecord(c->ev[stage][0], c->stream); }
     }
     ~StageTimer() {
@@ -273,7 +274,7 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity) {
 }
 
 int collect_timings(eincm_ctx* c) {
-    if (!(c->cflags & EINCM_CF_TIMING)) return EINCM_OK;
+    if (!(c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT))) return EINCM_OK;
     memset(&c->last_t, 0, sizeof c->last_t);
     for (int s = 0; s < EINCM_N_STAGES; ++s) {
         if (!c->ev_used[s]) continue;
@@ -312,7 +313,7 @@ int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_p
         if (rc) return rc;
     }
     for (int s = 0; s <= EINCM_N_STAGES; ++s) c->ev_used[s] = false;
-    const bool timing = (c->cflags & EINCM_CF_TIMING) != 0;
+    const bool timing = (c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)) != 0;
     if (timing) { (void)hipEventRecord(c->ev[EINCM_N_STAGES][0], c->stream); }
 
     EvalParams ep{};
@@ -752,7 +753,8 @@ int eincm_get_scaled_theta(eincm_ctx* c, double* T) {
 
 int eincm_get_timings(eincm_ctx* c, eincm_timings* t) {
     if (!c || !t) return EINCM_ERR_ARG;
-    if (!(c->cflags & EINCM_CF_TIMING)) return fail(c, EINCM_ERR_STATE, "context was created without EINCM_CF_TIMING");
+    if (!(c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)))
+        return fail(c, EINCM_ERR_STATE, "context was created without EINCM_CF_TIMING / EINCM_CF_TIMING_DOMINANT");
     *t = c->last_t;
     return EINCM_OK;
 }

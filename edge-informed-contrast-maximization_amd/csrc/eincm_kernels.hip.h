@@ -165,10 +165,12 @@ __device__ __forceinline__ Window item_window(const Geom& g, const Item& it, con
 __device__ __forceinline__ void warp_axis(int x, double v, double dt, int& ir, float& f) {
     const double w = (double)x - v * dt;
     const double r = rint(w);
-    f = (float)(w - r);                              // garbage when !ok, but then every tap is dropped
-    const bool ok = fabs(w) < 1.0e6;                 // |w| beyond any sensor (or NaN): every tap is dropped
-    ir = ok ? (int)r : -(1 << 24);
+    f = (float)(w - r);                              // garbage when the event is off-sensor, but then every tap is dropped
+    const int ri = (int)r;                           // v_cvt_i32_f64 saturates (NaN -> 0; a NaN theta is caught in k_final)
+    ir = ((unsigned)(ri + (1 << 20)) < (1u << 21)) ? ri : -(1 << 24);   // |w| beyond any sensor: every tap is dropped
 }
+
+struct EvReg { uint32_t xy; double t; double2 v; };   // one event in flight through the 3-stage pipeline of the event kernels
 
 // Separable 3-tap weights exp(-0.5*(d - f)^2), d = -1,0,1 (event_utils.py:52-56; the 1/(2*pi) is folded by the caller):
 //   exp(-0.5 (d-f)^2) = exp(-0.5 f^2) * exp(d f) * exp(-0.5 d^2).  Two v_exp_f32 + one v_rcp_f32 (1 ulp each).
@@ -298,57 +300,54 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk,
     int fshift = fix_shift(min(chunk, n));
     float FIX_SCALE = ldexpf(1.0f, fshift), FIX_INV = ldexpf(1.0f, -fshift);
 
-    // Two-deep software pipeline: while event j is splatted, the Theta gather of event j+1 and the (xy, t) loads of
-    // event j+2 are in flight (the loop is otherwise bound by two dependent global-load latencies per event).
+    // Three-stage software pipeline over the segment's events, unrolled x3 with renamed register sets (no rotation
+    // moves, so no forced vmcnt(0)): while event j is splatted, the Theta gather of event j+1 and the (xy, t) loads of
+    // event j+2 are in flight.  Without it the loop is bound by two dependent global-load latencies per event.
     auto theta_at = [&](uint32_t xy) -> double2 {
         return *reinterpret_cast<const double2*>(Th + ((size_t)(xy >> 16) * g.W + (xy & 0xffff)) * 2);
     };
     const int tid = threadIdx.x;
-    uint32_t xyA = (tid < n) ? exy[tid] : 0u;
-    double tA = (tid < n) ? et[tid] : 0.0;
-    uint32_t xyB = (tid + NT < n) ? exy[tid + NT] : 0u;
-    double tB = (tid + NT < n) ? et[tid + NT] : 0.0;
-    double2 vA = theta_at(xyA);
-    for (int j = 0; j < iters; ++j) {
-        const int e = j * NT + tid;
-        uint32_t xyC = 0u; double tC = 0.0;
-        if (e + 2 * NT < n) { xyC = exy[e + 2 * NT]; tC = et[e + 2 * NT]; }
-        const double2 vB = theta_at(xyB);           // xy = 0 (past the end) is pixel (0,0): a valid address
-        if (e < n) {
-            const double dt = tA - tau;
-            const int x = xyA & 0xffff, y = xyA >> 16;
-            int irx, iry; float fx, fy;
-            warp_axis(x, vA.x, dt, irx, fx);
-            warp_axis(y, vA.y, dt, iry, fy);
-            float kx[3], ky[3];
-            taps3(fx, kx[0], kx[1], kx[2]);
-            taps3(fy, ky[0], ky[1], ky[2]);
-            ky[0] *= INV_2PI * FIX_SCALE; ky[1] *= INV_2PI * FIX_SCALE; ky[2] *= INV_2PI * FIX_SCALE;
-            const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;        // window coords of the top-left tap
-            if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
-                uint32_t* p = ldsu + ly * wn.ww + lx;
+    auto load_ev = [&](EvReg& r, int e) { if (e < n) { r.xy = exy[e]; r.t = et[e]; } else { r.xy = 0u; r.t = 0.0; } };
+    auto splat_ev = [&](const EvReg& ev) {
+        const double dt = ev.t - tau;
+        const int x = ev.xy & 0xffff, y = ev.xy >> 16;
+        int irx, iry; float fx, fy;
+        warp_axis(x, ev.v.x, dt, irx, fx);
+        warp_axis(y, ev.v.y, dt, iry, fy);
+        float kx[3], ky[3];
+        taps3(fx, kx[0], kx[1], kx[2]);
+        taps3(fy, ky[0], ky[1], ky[2]);
+        ky[0] *= INV_2PI * FIX_SCALE; ky[1] *= INV_2PI * FIX_SCALE; ky[2] *= INV_2PI * FIX_SCALE;
+        const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;        // window coords of the top-left tap
+        if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
+            uint32_t* p = ldsu + ly * wn.ww + lx;
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
+            for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) atomicAdd(p + dy * wn.ww + dx, fix_u32(ky[dy], kx[dx]));
-                }
-            } else {
+                for (int dx = 0; dx < 3; ++dx) atomicAdd(p + dy * wn.ww + dx, fix_u32(ky[dy], kx[dx]));
+            }
+        } else {
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
+            for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const int cx = lx + dx, cy = ly + dy;
-                        if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
-                            atomicAdd(ldsu + cy * wn.ww + cx, fix_u32(ky[dy], kx[dx]));
-                        } else {
-                            const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
-                            if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, ky[dy] * kx[dx] * FIX_INV);
-                        }
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int cx = lx + dx, cy = ly + dy;
+                    if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
+                        atomicAdd(ldsu + cy * wn.ww + cx, fix_u32(ky[dy], kx[dx]));
+                    } else {
+                        const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
+                        if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, ky[dy] * kx[dx] * FIX_INV);
                     }
                 }
             }
         }
-        xyA = xyB; tA = tB; vA = vB; xyB = xyC; tB = tC;
+    };
+    // one pipeline step: cur is splatted, mid gets its Theta, nxt gets its (xy, t); j = iteration index of cur
+    auto step = [&](EvReg& cur, EvReg& mid, EvReg& nxt, int j) {
+        const int e = j * NT + tid;
+        load_ev(nxt, e + 2 * NT);
+        mid.v = theta_at(mid.xy);                   // xy = 0 (past the end) is pixel (0,0): a valid address
+        if (e < n) splat_ev(cur);
         if (multi && ((j + 1) % ipc == 0 || j + 1 == iters)) {     // chunk boundary (uniform): commit u32 -> f32 window
             __syncthreads();
             for (int i = tid; i < nwin; i += NT) {
@@ -359,6 +358,16 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk,
             fshift = fix_shift(min(chunk, n - (j + 1) * NT));
             FIX_SCALE = ldexpf(1.0f, fshift); FIX_INV = ldexpf(1.0f, -fshift);
         }
+    };
+    EvReg A, B, C;
+    load_ev(A, tid);
+    load_ev(B, tid + NT);
+    A.v = theta_at(A.xy);
+    C.xy = 0u; C.t = 0.0; C.v = make_double2(0.0, 0.0);
+    for (int j = 0; j < iters; j += 3) {
+        step(A, B, C, j);
+        if (j + 1 < iters) step(B, C, A, j + 1);
+        if (j + 2 < iters) step(C, A, B, j + 2);
     }
     if (!multi) __syncthreads();
     // row-wise flush: a wave walks one window row -> contiguous fp32 atomics on one image row
@@ -766,24 +775,13 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         return *reinterpret_cast<const double2*>(Th + ((size_t)(xy >> 16) * g.W + (xy & 0xffff)) * 2);
     };
     const int tid = threadIdx.x;
-    uint32_t xyA = (tid < n) ? exy[tid] : 0u;
-    double tA = (tid < n) ? et[tid] : 0.0;
-    uint32_t xyB = (tid + NT < n) ? exy[tid + NT] : 0u;
-    double tB = (tid + NT < n) ? et[tid + NT] : 0.0;
-    double2 vA = theta_at(xyA);
-    for (int j = 0; j < iters; ++j) {               // two-deep software pipeline, as in k_splat
-        const int e = j * NT + tid;
-        uint32_t xyC = 0u; double tC = 0.0;
-        if (e + 2 * NT < n) { xyC = exy[e + 2 * NT]; tC = et[e + 2 * NT]; }
-        const double2 vB = theta_at(xyB);
-        const uint32_t xy = xyA; const double tcur = tA; const double2 v = vA;
-        xyA = xyB; tA = tB; vA = vB; xyB = xyC; tB = tC;
-        if (e >= n) continue;
-        const double dt = tcur - tau;
-        const int x = xy & 0xffff, y = xy >> 16;
+    auto load_ev = [&](EvReg& r, int e) { if (e < n) { r.xy = exy[e]; r.t = et[e]; } else { r.xy = 0u; r.t = 0.0; } };
+    auto gather_ev = [&](const EvReg& ev) {
+        const double dt = ev.t - tau;
+        const int x = ev.xy & 0xffff, y = ev.xy >> 16;
         int irx, iry; float fx, fy;
-        warp_axis(x, v.x, dt, irx, fx);
-        warp_axis(y, v.y, dt, iry, fy);
+        warp_axis(x, ev.v.x, dt, irx, fx);
+        warp_axis(y, ev.v.y, dt, iry, fy);
         float kx[3], ky[3];
         taps3(fx, kx[0], kx[1], kx[2]);
         taps3(fy, ky[0], ky[1], ky[2]);
@@ -832,6 +830,23 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         double* a = accum + ((y - y0) * TS + (x - x0)) * 2;
         atomicAdd(a, -dt * (double)gwx);
         atomicAdd(a + 1, -dt * (double)gwy);
+    };
+    // three-stage pipeline with renamed register sets, as in k_splat
+    auto step = [&](EvReg& cur, EvReg& mid, EvReg& nxt, int j) {
+        const int e = j * NT + tid;
+        load_ev(nxt, e + 2 * NT);
+        mid.v = theta_at(mid.xy);
+        if (e < n) gather_ev(cur);
+    };
+    EvReg A, B, C;
+    load_ev(A, tid);
+    load_ev(B, tid + NT);
+    A.v = theta_at(A.xy);
+    C.xy = 0u; C.t = 0.0; C.v = make_double2(0.0, 0.0);
+    for (int j = 0; j < iters; j += 3) {
+        step(A, B, C, j);
+        if (j + 1 < iters) step(B, C, A, j + 1);
+        if (j + 2 < iters) step(C, A, B, j + 2);
     }
     __syncthreads();
     float* __restrict__ gT = gTheta + (size_t)it.win * g.H * g.W * 2;

@@ -39,8 +39,10 @@ class Engine:
         self.H, self.W = int(sensor_size[0]), int(sensor_size[1])
         self.max_windows = int(max_windows)
         self.max_refs = int(max_refs)
+        # timing: False | True (every stage, ~10 % slower) | 'dominant' (only k_splat + whole evaluation)
+        flags = 0 if not timing else (L.CF_TIMING_DOMINANT if timing == 'dominant' else L.CF_TIMING)
         self._ctx = self._lib.eincm_create(int(device), self.H, self.W, int(max_refs), int(max_windows),
-                                           int(max_events_total), L.CF_TIMING if timing else 0)
+                                           int(max_events_total), flags)
         if not self._ctx:
             raise EincmError(L.ERR_HIP, self._lib.eincm_last_error(None).decode())
         self.B = 0

@@ -48,7 +48,8 @@ extern "C" {
                                       TV at any gamma (losses.py:75), FWL (losses.py:84) */
 
 /* eincm_create flags */
-#define EINCM_CF_TIMING     1u     /* bracket every kernel with HIP events (eincm_get_timings) */
+#define EINCM_CF_TIMING     1u     /* bracket every kernel with HIP events (eincm_get_timings); costs ~10 % of a step */
+#define EINCM_CF_TIMING_DOMINANT 2u /* bracket only the dominant kernel (k_splat) and the whole evaluation: 4 event records */
 
 typedef struct eincm_ctx eincm_ctx;
 
