@@ -182,10 +182,10 @@ void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_edges); F(c->d_edge_ts); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
-    F(c->d_divparts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); F(c->d_gth); F(c->d_grad); F(c->d_AH); F(c->d_AW);
+    F(c->d_divparts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
     F(c->d_rowtap); F(c->d_coltap);
     auto FH = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
-    FH(c->h_theta); FH(c->h_grad); FH(c->h_outs); FH(c->h_wc);
+    FH(c->h_theta); FH(c->h_outs); c->h_grad = nullptr; FH(c->h_wc);
     if (c->have_events) {
         for (int i = 0; i <= EINCM_N_STAGES; ++i) { (void)hipEventDestroy(c->ev[i][0]); (void)hipEventDestroy(c->ev[i][1]); }
         c->have_events = false;
@@ -247,16 +247,23 @@ unsigned event_grid(const eincm_ctx* c) { return (unsigned)(((c->n_items + NXCD 
 
 // Launch the forward half: theta -> Theta -> IWE stack -> image statistics.
 // theta must already be in d_theta_in (identity: (B,H,W,2); else (B,h,w,2)).
-int launch_forward(eincm_ctx* c, int h, int w, bool identity) {
+int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool want_grad, const double* theta_host) {
     const Geom& g = c->g;
-    const size_t img = (size_t)g.H * g.W;
-    {
-        StageTimer t(c, EINCM_STAGE_CLEAR);
-        HIPCHK(c, hipMemsetAsync(c->d_iwe, 0, (size_t)g.B * g.R * img * sizeof(float), c->stream));
+    const size_t nth = (size_t)h * w * 2;
+    const bool use_arg = !identity && (size_t)g.B * nth <= (size_t)THETA_ARG_MAX;
+    ThetaArg targ;
+    if (use_arg) {
+        memcpy(targ.v, theta_host, (size_t)g.B * nth * sizeof(double));     // theta rides in the kernel arguments
+    } else {
+        StageTimer t(c, EINCM_STAGE_COPY);
+        memcpy(c->h_theta, theta_host, (size_t)g.B * nth * sizeof(double));
+        HIPCHK(c, hipMemcpyAsync(c->d_theta_in, c->h_theta, (size_t)g.B * nth * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
     {
         StageTimer t(c, EINCM_STAGE_THETA);
-        hipLaunchKernelGGL(k_theta, dim3(g.ntiles, g.B), dim3(NT), 0, c->stream, g, h, w, identity ? 1 : 0,
+        hipLaunchKernelGGL(k_theta, dim3(g.ntiles, g.B), dim3(NT), 0, c->stream, g, h, w, identity ? 1 : 0, use_arg ? 1 : 0, targ,
+                           c->d_iwe, want_grad ? c->d_gTheta : nullptr, (want_grad && !identity) ? c->d_gth : nullptr,
+                           (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap,
                            c->d_theta_in, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_Theta, c->d_tmm);
     }
     {
@@ -324,12 +331,7 @@ int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_p
     ep.use_tv_grad = (ep.want_tv && p->gamma != 0.0 && want_grad) ? 1 : 0;
     ep.h = h; ep.w = w; ep.identity = identity ? 1 : 0;
 
-    {
-        StageTimer t(c, EINCM_STAGE_COPY);
-        memcpy(c->h_theta, theta_host, (size_t)g.B * nth * sizeof(double));
-        HIPCHK(c, hipMemcpyAsync(c->d_theta_in, c->h_theta, (size_t)g.B * nth * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    }
-    int rc = launch_forward(c, h, w, identity);
+    int rc = launch_forward(c, h, w, identity, want_grad, theta_host);
     if (rc) return rc;
 
     if (ep.want_div) {
@@ -351,34 +353,37 @@ int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_p
         }
         {
             StageTimer t(c, EINCM_STAGE_GATHER);
-            HIPCHK(c, hipMemsetAsync(c->d_gTheta, 0, (size_t)g.B * img * 2 * sizeof(float), c->stream));
             if (c->n_items > 0)
                 hipLaunchKernelGGL(k_gather, dim3(event_grid(c)), dim3(NT), WIN_CAP * sizeof(float) + TS * TS * 2 * sizeof(double), c->stream,
                                g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta);
         }
         if (!identity) {
             StageTimer t(c, EINCM_STAGE_PROJECT);
-            HIPCHK(c, hipMemsetAsync(c->d_gth, 0, (size_t)2 * g.B * c->coarse_cap * sizeof(double), c->stream));
-            // accumulators are laid out (B, nth) inside each half
+            // accumulators: two halves (event gradient | TV gradient), each (maxB, coarse_cap), zeroed by k_theta
             hipLaunchKernelGGL(k_project, dim3(g.ntiles, g.B, ep.use_tv_grad ? 2 : 1), dim3(NT), 0, c->stream, g, h, w,
-                               c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_gTheta, c->d_tvg, c->d_gth,
-                               c->d_gth + (size_t)g.B * c->coarse_cap);
+                               (int)c->coarse_cap, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_gTheta, c->d_tvg, c->d_gth,
+                               c->d_gth + (size_t)c->maxB * c->coarse_cap);
         }
     }
     {
         StageTimer t(c, EINCM_STAGE_FINAL);
         hipLaunchKernelGGL(k_final, dim3(g.B), dim3(NT), 0, c->stream, g, ep, c->d_parts, c->d_divparts, c->d_tvparts,
-                           c->d_tmm, c->d_wc, c->d_gth, c->d_gth + (size_t)g.B * c->coarse_cap, c->d_outs, c->d_grad,
-                           want_grad ? 1 : 0);
+                           c->d_tmm, c->d_wc, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap,
+                           c->d_outs, c->d_grad, want_grad ? 1 : 0);
         if (want_grad && identity) {
             hipLaunchKernelGGL(k_final_dense, dim3(256, g.B), dim3(NT), 0, c->stream, g, ep.use_tv_grad, c->d_gTheta,
                                c->d_tvg, c->d_outs, c->d_grad);
         }
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal), hipMemcpyDeviceToHost, c->stream));
-    if (want_grad)
-        HIPCHK(c, hipMemcpyAsync(c->h_grad, c->d_grad, (size_t)g.B * nth * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (want_grad && g.B == c->maxB) {      // outs and grad are contiguous: one copy
+        HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal) + (size_t)g.B * nth * sizeof(double),
+                                 hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal), hipMemcpyDeviceToHost, c->stream));
+        if (want_grad)
+            HIPCHK(c, hipMemcpyAsync(c->h_grad, c->d_grad, (size_t)g.B * nth * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
     if (timing) { (void)hipEventRecord(c->ev[EINCM_N_STAGES][1], c->stream); c->ev_used[EINCM_N_STAGES] = true; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     rc = collect_timings(c);
@@ -488,14 +493,20 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_divparts, B * R * ntiles));
     TRY(dalloc(&c->d_tvparts, B * ntiles * 3));
     TRY(dalloc(&c->d_wc, B));
-    TRY(dalloc(&c->d_outs, B));
+    {   // one device block and one pinned block: [OutScal x B | grad (B,H,W,2)] -> a single D2H copy per evaluation
+        char* blk = nullptr;
+        TRY(hipMalloc(reinterpret_cast<void**>(&blk), B * sizeof(OutScal) + B * img * 2 * sizeof(double)));
+        c->d_outs = reinterpret_cast<OutScal*>(blk);
+        c->d_grad = reinterpret_cast<double*>(blk + B * sizeof(OutScal));
+        char* hblk = nullptr;
+        TRY(hipHostMalloc(reinterpret_cast<void**>(&hblk), B * sizeof(OutScal) + B * img * 2 * sizeof(double), hipHostMallocDefault));
+        c->h_outs = reinterpret_cast<OutScal*>(hblk);
+        c->h_grad = reinterpret_cast<double*>(hblk + B * sizeof(OutScal));
+    }
     TRY(dalloc(&c->d_gth, 2 * B * (size_t)c->coarse_cap));
-    TRY(dalloc(&c->d_grad, B * img * 2));
     TRY(dalloc(&c->d_rowtap, (size_t)H));
     TRY(dalloc(&c->d_coltap, (size_t)W));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_theta), B * img * 2 * sizeof(double), hipHostMallocDefault));
-    TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_grad), B * img * 2 * sizeof(double), hipHostMallocDefault));
-    TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_outs), B * sizeof(OutScal), hipHostMallocDefault));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_wc), B * sizeof(WinConst), hipHostMallocDefault));
     for (int i = 0; i <= EINCM_N_STAGES; ++i) { TRY(hipEventCreate(&c->ev[i][0])); TRY(hipEventCreate(&c->ev[i][1])); c->ev_used[i] = false; }
     c->have_events = true;

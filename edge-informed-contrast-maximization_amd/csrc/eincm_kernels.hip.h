@@ -78,6 +78,9 @@ struct EvalParams {
     int h, w, identity;
 };
 
+constexpr int THETA_ARG_MAX = 128;    // doubles of theta that ride in the kernel arguments instead of an H2D copy
+struct ThetaArg { double v[THETA_ARG_MAX]; };
+
 struct OutScal {                  // per-window result block written by k_final
     double value, mean_rel_corr, mean_rel_contrast, mean_rel_div, tv, tv_scale, nonfinite, _pad;
     double corr[16], contrast_gm[16], var[16], div[16];
@@ -192,7 +195,10 @@ __device__ __forceinline__ uint32_t fix_u32(float a, float b) { return (uint32_t
 // k_theta: Theta = A_H theta A_W^T per channel, and per-tile velocity bounds.
 // grid (ntiles, B).  identity: theta already is (H,W,2).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity,
+__global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity, int use_arg, ThetaArg targ,
+        float* __restrict__ iwe,               // (B,R,H,W)  cleared here (one launch instead of three memsets)
+        float* __restrict__ gTheta,            // (B,H,W,2)  cleared here, or nullptr (forward only)
+        double* __restrict__ gth, size_t gth_half_stride, int gth_cap,   // coarse accumulators (2 halves, B, gth_cap) or nullptr
         const double* __restrict__ theta,      // (B,h,w,2)
         const double* __restrict__ AH,         // (H,h)
         const double* __restrict__ AW,         // (W,w)
@@ -207,13 +213,38 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const double* th = theta + (size_t)b * h * w * 2;
     double* Th = Theta + (size_t)b * g.H * g.W * 2;
+    // fused clears: this block's tile of every IWE image and of dL/dTheta; block 0 of each window its coarse accumulators
+    for (int p = threadIdx.x; p < TS * TS; p += NT) {
+        const int y = ty * TS + p / TS, x = tx * TS + p % TS;
+        if (y >= g.H || x >= g.W) continue;
+        const size_t o = (size_t)y * g.W + x;
+        for (int r = 0; r < g.R; ++r) iwe[((size_t)b * g.R + r) * g.H * g.W + o] = 0.0f;
+        if (gTheta) *reinterpret_cast<float2*>(gTheta + ((size_t)b * g.H * g.W + o) * 2) = make_float2(0.0f, 0.0f);
+    }
+    if (gth && tile == 0) {
+        const int n = min(h * w * 2, gth_cap);
+        for (int i = threadIdx.x; i < n; i += NT) { gth[(size_t)b * gth_cap + i] = 0.0; gth[gth_half_stride + (size_t)b * gth_cap + i] = 0.0; }
+    }
     double mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
     bool nan = false;
     for (int p = threadIdx.x; p < TS * TS; p += NT) {
         const int y = ty * TS + p / TS, x = tx * TS + p % TS;
         if (y >= g.H || x >= g.W) continue;
         double vx, vy;
-        if (identity) {
+        if (use_arg) {
+            const int2 rt = rowtap[y], ct = coltap[x];
+            vx = 0.0; vy = 0.0;
+            for (int i = rt.x; i < rt.y; ++i) {
+                const double a = AH[(size_t)y * h + i];
+                double sx = 0.0, sy = 0.0;
+                for (int j = ct.x; j < ct.y; ++j) {
+                    const double bw = AW[(size_t)x * w + j];
+                    const int o = ((b * h + i) * w + j) * 2;
+                    sx += bw * targ.v[o]; sy += bw * targ.v[o + 1];
+                }
+                vx += a * sx; vy += a * sy;
+            }
+        } else if (identity) {
             const double2 v = *reinterpret_cast<const double2*>(th + ((size_t)y * g.W + x) * 2);
             vx = v.x; vy = v.y;
         } else {
@@ -999,15 +1030,19 @@ __global__ __launch_bounds__(NT) void k_tv(Geom g, const double* __restrict__ Th
 // ------------------------------------------------------------------------------------------------
 // k_project: dL/dtheta[i,j,c] += sum_{y,x in tile} AH[y,i] AW[x,j] src[y,x,c]   (adjoint of k_theta).
 // grid (ntiles, B, nsrc): z = 0 projects the fp32 event gradient gTheta, z = 1 the fp64 TV gradient image.
+// One cell under the tile (2-DoF theta): block sum.  Several cells: every pixel adds its <= taps x taps contributions
+// into LDS cell accumulators (ds_add_f64), flushed with global_atomic_add_f64.  More cells than PROJ_CELLS: straight to HBM.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w,
+constexpr int PROJ_CELLS = 1024;
+__global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap,
         const double* __restrict__ AH, const double* __restrict__ AW,
         const int2* __restrict__ rowtap, const int2* __restrict__ coltap,
         const float* __restrict__ gTheta, const double* __restrict__ tvg,
-        double* __restrict__ gth_main, double* __restrict__ gth_tv)   // (B,h,w,2) each, zeroed
+        double* __restrict__ gth_main, double* __restrict__ gth_tv)   // (B,cap) each, zeroed by k_theta
 {
     __shared__ double scratch[NWAVE];
     __shared__ int rng[4];
+    __shared__ double cells[PROJ_CELLS * 2];
     const int tile = blockIdx.x, b = blockIdx.y, src = blockIdx.z;
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
@@ -1020,36 +1055,51 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w,
     }
     __syncthreads();
     const int ilo = rng[0], ihi = rng[1], jlo = rng[2], jhi = rng[3];
-    // this thread's pixels (TS*TS/NT = 4 slots; out-of-image slots carry zeros)
-    constexpr int NS = TS * TS / NT;
-    double vx[NS], vy[NS]; int py[NS], px[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        const int p = threadIdx.x + k * NT;
+    const int ni = max(ihi - ilo, 0), nj = max(jhi - jlo, 0), ncell = ni * nj;
+    double* __restrict__ out = (src == 0 ? gth_main : gth_tv) + (size_t)b * cap;
+    const bool use_lds = (ncell > 1 && ncell <= PROJ_CELLS);
+    if (use_lds) {
+        for (int i = threadIdx.x; i < ncell * 2; i += NT) cells[i] = 0.0;
+        __syncthreads();
+    }
+    double sx1 = 0.0, sy1 = 0.0;                    // single-cell path
+    for (int p = threadIdx.x; p < TS * TS; p += NT) {
         const int y = y0 + p / TS, x = x0 + p % TS;
-        const bool in = (y < g.H && x < g.W);
-        py[k] = in ? y : y0; px[k] = in ? x : x0;
-        vx[k] = 0.0; vy[k] = 0.0;
-        if (in) {
-            const size_t o = ((size_t)b * g.H * g.W + (size_t)y * g.W + x) * 2;
-            if (src == 0) { vx[k] = (double)gTheta[o]; vy[k] = (double)gTheta[o + 1]; }
-            else { vx[k] = tvg[o]; vy[k] = tvg[o + 1]; }
+        if (y >= g.H || x >= g.W) continue;
+        const size_t o = ((size_t)b * g.H * g.W + (size_t)y * g.W + x) * 2;
+        double vx, vy;
+        if (src == 0) { vx = (double)gTheta[o]; vy = (double)gTheta[o + 1]; }
+        else { vx = tvg[o]; vy = tvg[o + 1]; }
+        if (vx == 0.0 && vy == 0.0) continue;
+        const int2 rt = rowtap[y], ct = coltap[x];
+        for (int i = rt.x; i < rt.y; ++i) {
+            const double a = AH[(size_t)y * h + i];
+            for (int j = ct.x; j < ct.y; ++j) {
+                const double wt = a * AW[(size_t)x * w + j];
+                if (ncell == 1) { sx1 += wt * vx; sy1 += wt * vy; }
+                else if (use_lds) {
+                    double* c = cells + ((i - ilo) * nj + (j - jlo)) * 2;
+                    atomicAdd(c, wt * vx); atomicAdd(c + 1, wt * vy);
+                } else {
+                    atomicAdd(out + ((size_t)i * w + j) * 2, wt * vx); atomicAdd(out + ((size_t)i * w + j) * 2 + 1, wt * vy);
+                }
+            }
         }
     }
-    double* __restrict__ out = (src == 0 ? gth_main : gth_tv) + (size_t)b * h * w * 2;
-    for (int i = ilo; i < ihi; ++i) {
-        for (int j = jlo; j < jhi; ++j) {
-            double sx = 0.0, sy = 0.0;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const double wt = AH[(size_t)py[k] * h + i] * AW[(size_t)px[k] * w + j];
-                sx += wt * vx[k]; sy += wt * vy[k];
-            }
-            sx = block_sum(sx, scratch);
-            sy = block_sum(sy, scratch);
-            if (threadIdx.x == 0) {
-                if (sx != 0.0) atomicAdd(out + ((size_t)i * w + j) * 2, sx);
-                if (sy != 0.0) atomicAdd(out + ((size_t)i * w + j) * 2 + 1, sy);
+    if (ncell == 1) {
+        sx1 = block_sum(sx1, scratch);
+        sy1 = block_sum(sy1, scratch);
+        if (threadIdx.x == 0) {
+            if (sx1 != 0.0) atomicAdd(out + ((size_t)ilo * w + jlo) * 2, sx1);
+            if (sy1 != 0.0) atomicAdd(out + ((size_t)ilo * w + jlo) * 2 + 1, sy1);
+        }
+    } else if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < ncell * 2; i += NT) {
+            const double v = cells[i];
+            if (v != 0.0) {
+                const int c = i & 1, ci = (i >> 1) / nj, cj = (i >> 1) % nj;
+                atomicAdd(out + ((size_t)(ilo + ci) * w + (jlo + cj)) * 2 + c, v);
             }
         }
     }
@@ -1063,7 +1113,7 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w,
 __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
         const StatPart* __restrict__ parts, const double* __restrict__ divparts, const double* __restrict__ tvparts,
         const double* __restrict__ tmm, const WinConst* __restrict__ wc,
-        const double* __restrict__ gth_main, const double* __restrict__ gth_tv,
+        const double* __restrict__ gth_main, const double* __restrict__ gth_tv, int gth_cap,
         OutScal* __restrict__ outs, double* __restrict__ grad_out, int want_grad)
 {
     __shared__ double scratch[NWAVE];
@@ -1139,8 +1189,8 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
         const double s = sh_tvscale;
         const int n = ep.h * ep.w * 2;
         for (int i = threadIdx.x; i < n; i += NT) {
-            double v = gth_main[(size_t)b * n + i];
-            if (ep.use_tv_grad) v += s * gth_tv[(size_t)b * n + i];
+            double v = gth_main[(size_t)b * gth_cap + i];
+            if (ep.use_tv_grad) v += s * gth_tv[(size_t)b * gth_cap + i];
             grad_out[(size_t)b * n + i] = v;
         }
     }
