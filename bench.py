@@ -58,13 +58,25 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % ndev                 # == local_rank on a real node; lets 2 ranks rehearse on a 1-GPU box
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    backend = os.environ.get('EINCM_BENCH_BACKEND', 'nccl')      # 'gloo' only for the single-GPU rehearsal
+    red_dev = dev if backend == 'nccl' else torch.device('cpu')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import __graft_entry__ as ge
+    if world > 1:
+        # one builder per node (hipcc writes the .so in place); everyone else loads it after the barrier
+        if local_rank == 0:
+            ge.build()
+        dist.barrier()
     ge.build()
     synth = importlib.import_module('edge-informed-contrast-maximization_amd.synth')
     engine = importlib.import_module('edge-informed-contrast-maximization_amd.engine')
@@ -84,7 +96,7 @@ def main():
     else:
         base = np.stack([synth.theta_near_truth(1000 * rank + b, wn, (h, w)) for b, wn in enumerate(wins)])
     n_theta = a.steps + a.warmup
-    eng = engine.Engine((H, W), B * N, max_refs=R, max_windows=B, device=local_rank, timing='dominant')
+    eng = engine.Engine((H, W), B * N, max_refs=R, max_windows=B, device=dev_index, timing='dominant')
     t0 = time.perf_counter()
     eng.set_windows([(wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts']) for wn in wins])
     t_stage = time.perf_counter() - t0
@@ -95,7 +107,7 @@ def main():
 
     def step(k):
         v, g, _ = eng.loss_grad(theta_at(k), p)
-        tot = sharding.allreduce_batch_loss(v, dev) if world > 1 else float(v.sum())
+        tot = sharding.allreduce_batch_loss(v, red_dev) if world > 1 else float(v.sum())
         return tot, v, g
 
     for k in range(a.warmup):
@@ -114,7 +126,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert np.all(np.isfinite(v)) and np.all(np.isfinite(g)), 'non-finite loss/grad in the timed region'
@@ -127,7 +139,7 @@ def main():
     diag = {}
     if rank == 0:
         eng.close()
-        eng = engine.Engine((H, W), B * N, max_refs=R, max_windows=B, device=local_rank, timing=True)
+        eng = engine.Engine((H, W), B * N, max_refs=R, max_windows=B, device=dev_index, timing=True)
         eng.set_windows([(wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts']) for wn in wins])
         nd = min(5, a.steps)
         for k in range(2 + nd):
@@ -179,7 +191,7 @@ def main():
     # ---- single-window latency (second half of the metric: loss+grad eval ms at 1e6 events) ----
     if rank == 0 and not a.no_latency:
         wn = wins[0]
-        with engine.Engine((H, W), N, max_refs=R, max_windows=1, device=local_rank) as e1:
+        with engine.Engine((H, W), N, max_refs=R, max_windows=1, device=dev_index) as e1:
             e1.set_window(wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts'])
             for k in range(3):
                 e1.loss_grad(theta_at(k)[0], p)
