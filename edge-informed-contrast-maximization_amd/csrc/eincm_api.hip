@@ -18,6 +18,7 @@
 
 #include "eincm.h"
 #include "eincm_kernels.hip.h"
+#include "eincm_binning.hip.h"
 
 using namespace eincm;
 
@@ -54,6 +55,13 @@ struct eincm_ctx {
     uint32_t* d_xy = nullptr;      // (maxN) x | y<<16, binned
     double* d_t = nullptr;         // (maxN)
     Item* d_items = nullptr;       // (max_items)
+    // device-side staging (eincm_binning.hip.h)
+    int16_t* d_raw_x = nullptr; int16_t* d_raw_y = nullptr; double* d_raw_t = nullptr;   // (maxN) events as handed over
+    BinBlock* d_binblocks = nullptr; int32_t* d_win_blk = nullptr; uint32_t* d_blockhist = nullptr;
+    int32_t* d_tilecount = nullptr; int32_t* d_tilebase = nullptr; int32_t* d_itembase = nullptr; int32_t* d_bin_misc = nullptr;
+    double* d_edges_raw = nullptr; double* d_edge_moments = nullptr;
+    int64_t max_binblocks = 0;
+    bool host_binning = false;
     int64_t max_items = 0;
     float* d_edges = nullptr;      // (B,R,H,W)
     double* d_edge_ts = nullptr;   // (B,R)
@@ -180,7 +188,8 @@ void multi_ref_weights(int R, double* w) {
 
 void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_edges); F(c->d_edge_ts); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
+    F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
+    F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
     F(c->d_divparts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
     F(c->d_rowtap); F(c->d_coltap);
@@ -478,6 +487,22 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_xy, (size_t)max_events_total));
     TRY(dalloc(&c->d_t, (size_t)max_events_total));
     TRY(dalloc(&c->d_items, (size_t)c->max_items));
+    c->host_binning = (ntiles > BIN_MAX_TILES) || (getenv("EINCM_HOST_BINNING") != nullptr);
+    if (!c->host_binning) {
+        c->max_binblocks = max_events_total / BIN_CHUNK + (int64_t)B + 1;
+        TRY(dalloc(&c->d_raw_x, (size_t)max_events_total));
+        TRY(dalloc(&c->d_raw_y, (size_t)max_events_total));
+        TRY(dalloc(&c->d_raw_t, (size_t)max_events_total));
+        TRY(dalloc(&c->d_binblocks, (size_t)c->max_binblocks));
+        TRY(dalloc(&c->d_win_blk, B + 1));
+        TRY(dalloc(&c->d_blockhist, (size_t)c->max_binblocks * ntiles));
+        TRY(dalloc(&c->d_tilecount, B * ntiles));
+        TRY(dalloc(&c->d_tilebase, B * ntiles));
+        TRY(dalloc(&c->d_itembase, B * ntiles));
+        TRY(dalloc(&c->d_bin_misc, (size_t)8));
+        TRY(dalloc(&c->d_edges_raw, B * R * img));
+        TRY(dalloc(&c->d_edge_moments, B * R * 2));
+    }
     TRY(dalloc(&c->d_edges, B * R * img));
     TRY(dalloc(&c->d_edge_ts, B * R));
     TRY(dalloc(&c->d_iwe, B * R * img));
@@ -550,7 +575,83 @@ int eincm_set_windows(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_
         seg = (int)std::min<int64_t>(16384, std::max<int64_t>(256, ((per + 255) / 256) * 256));
     }
     c->seg_used = seg;
-    // ---- bin by (window, source tile), stable in the input (time) order; cut bins into segments ----
+    const size_t img = (size_t)H * W;
+    for (int b = 0; b < n_windows; ++b) {
+        memset(&c->h_wc[b], 0, sizeof(WinConst));
+        multi_ref_weights(n_refs, c->h_wc[b].mrw);
+        for (int r = 0; r < n_refs; ++r)
+            if (!std::isfinite(edge_ts[b * n_refs + r])) return fail(c, EINCM_ERR_ARG, "edge_ts[%d,%d] is not finite", b, r);
+    }
+    int n_items_total = 0;
+    if (!c->host_binning) {
+        // ---- device path: counting sort by (window, source tile) on the GPU (eincm_binning.hip.h) ----
+        std::vector<BinBlock> blks;
+        std::vector<int32_t> win_blk((size_t)n_windows + 1);
+        int64_t base = 0;
+        for (int b = 0; b < n_windows; ++b) {
+            win_blk[b] = (int32_t)blks.size();
+            for (int64_t s0 = 0; s0 < n_events[b]; s0 += BIN_CHUNK) {
+                BinBlock bb; bb.win = b; bb.start = (int32_t)(base + s0); bb.count = (int32_t)std::min<int64_t>(BIN_CHUNK, n_events[b] - s0);
+                bb.first_blk = win_blk[b];
+                blks.push_back(bb);
+            }
+            base += n_events[b];
+        }
+        win_blk[n_windows] = (int32_t)blks.size();
+        const int nblk = (int)blks.size();
+        if (nblk > c->max_binblocks) return fail(c, EINCM_ERR_ARG, "internal: %d staging blocks exceed capacity", nblk);
+        int32_t misc_init[4] = {0, 0, 0x7fffffff, 0x7fffffff};                      // totals[2], err[2]
+        HIPCHK(c, hipMemcpyAsync(c->d_bin_misc, misc_init, sizeof misc_init, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_win_blk, win_blk.data(), win_blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_edges_raw, edges, (size_t)n_windows * n_refs * img * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_edge_moments, 0, (size_t)n_windows * n_refs * 2 * sizeof(double), c->stream));
+        hipLaunchKernelGGL(k_edges, dim3(32, n_refs, n_windows), dim3(NT), 0, c->stream, g, c->d_edges_raw, c->d_edges, c->d_edge_moments);
+        if (nblk > 0) {
+            HIPCHK(c, hipMemcpyAsync(c->d_binblocks, blks.data(), blks.size() * sizeof(BinBlock), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_raw_x, xs, (size_t)N * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_raw_y, ys, (size_t)N * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_raw_t, ts, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_bin_hist, dim3(nblk), dim3(NT), g.ntiles * sizeof(uint32_t), c->stream, g, c->d_binblocks, c->d_raw_x, c->d_raw_y,
+                               c->d_raw_t, c->d_blockhist, c->d_bin_misc + 2);
+        } else {
+            HIPCHK(c, hipMemsetAsync(c->d_blockhist, 0, sizeof(uint32_t), c->stream));
+        }
+        const int M = n_windows * g.ntiles;
+        hipLaunchKernelGGL(k_bin_scan, dim3((M + 255) / 256), dim3(256), 0, c->stream, g, c->d_win_blk, c->d_blockhist, c->d_tilecount);
+        hipLaunchKernelGGL(k_bin_tilescan, dim3(1), dim3(1024), 0, c->stream, M, seg, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_bin_misc);
+        HIPCHK(c, hipGetLastError());
+        int32_t misc[4];
+        std::vector<double> mom((size_t)n_windows * n_refs * 2);
+        HIPCHK(c, hipMemcpyAsync(misc, c->d_bin_misc, sizeof misc, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(mom.data(), c->d_edge_moments, mom.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (misc[2] != 0x7fffffff) {
+            const int64_t e = misc[2];
+            int b = 0; int64_t off = e;
+            while (b < n_windows - 1 && off >= n_events[b]) { off -= n_events[b]; ++b; }
+            return fail(c, EINCM_ERR_ARG, "event %lld of window %d at (x=%d, y=%d) outside the %dx%d sensor", (long long)off, b,
+                        (int)xs[e], (int)ys[e], H, W);
+        }
+        if (misc[3] != 0x7fffffff) {
+            const int64_t e = misc[3];
+            int b = 0; int64_t off = e;
+            while (b < n_windows - 1 && off >= n_events[b]) { off -= n_events[b]; ++b; }
+            return fail(c, EINCM_ERR_ARG, "event %lld of window %d has a non-finite timestamp", (long long)off, b);
+        }
+        n_items_total = misc[1];
+        if (n_items_total > c->max_items) return fail(c, EINCM_ERR_ARG, "internal: %d segments exceed capacity", n_items_total);
+        for (int b = 0; b < n_windows; ++b)
+            for (int r = 0; r < n_refs; ++r) { c->h_wc[b].sE[r] = mom[((size_t)b * n_refs + r) * 2]; c->h_wc[b].sEE[r] = mom[((size_t)b * n_refs + r) * 2 + 1]; }
+        if (nblk > 0) {
+            hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(NT), g.ntiles * sizeof(uint32_t), c->stream, g, c->d_binblocks, c->d_raw_x, c->d_raw_y,
+                               c->d_raw_t, c->d_blockhist, c->d_tilebase, c->d_xy, c->d_t);
+            hipLaunchKernelGGL(k_items, dim3((M + 255) / 256), dim3(256), 0, c->stream, g, seg, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_items);
+            if (n_items_total > 0)
+                hipLaunchKernelGGL(k_seg_minmax, dim3(std::min(n_items_total, 4096)), dim3(NT), 0, c->stream, n_items_total, c->d_items, c->d_t);
+            HIPCHK(c, hipGetLastError());
+        }
+    } else {
+    // ---- host path (sensors with more tiles than the LDS histogram holds, or EINCM_HOST_BINNING=1): stable counting sort ----
     std::vector<uint32_t> sxy((size_t)std::max<int64_t>(N, 1));
     std::vector<double> st((size_t)std::max<int64_t>(N, 1));
     std::vector<Item> items;
@@ -589,21 +690,16 @@ int eincm_set_windows(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_
         base += n;
     }
     if ((int64_t)items.size() > c->max_items) return fail(c, EINCM_ERR_ARG, "internal: %zu work items exceed capacity", items.size());
-
-    // ---- edges -> fp32 (+ their moments in fp64 of the stored values), constants, uploads ----
-    const size_t img = (size_t)H * W;
+    n_items_total = (int)items.size();
     std::vector<float> ef((size_t)n_windows * n_refs * img);
     for (int b = 0; b < n_windows; ++b) {
         WinConst& wc = c->h_wc[b];
-        memset(&wc, 0, sizeof wc);
-        multi_ref_weights(n_refs, wc.mrw);
         for (int r = 0; r < n_refs; ++r) {
             const double* e = edges + ((size_t)b * n_refs + r) * img;
             float* o = ef.data() + ((size_t)b * n_refs + r) * img;
             double s = 0.0, ss = 0.0;
             for (size_t i = 0; i < img; ++i) { const float f = (float)e[i]; o[i] = f; s += (double)f; ss += (double)f * (double)f; }
             wc.sE[r] = s; wc.sEE[r] = ss;
-            if (!std::isfinite(edge_ts[b * n_refs + r])) return fail(c, EINCM_ERR_ARG, "edge_ts[%d,%d] is not finite", b, r);
         }
     }
     if (N > 0) {
@@ -613,10 +709,12 @@ int eincm_set_windows(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_
     if (!items.empty())
         HIPCHK(c, hipMemcpyAsync(c->d_items, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_edges, ef.data(), ef.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // host vectors go out of scope
+    }
     HIPCHK(c, hipMemcpyAsync(c->d_edge_ts, edge_ts, (size_t)n_windows * n_refs * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_mask, 0, (size_t)n_windows * img, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->g = g; c->n_items = (int)items.size(); c->n_events = N;
+    c->g = g; c->n_items = n_items_total; c->n_events = N;
     c->win_events.assign(n_events, n_events + n_windows);
     if (c->n_items > 0) {
         hipLaunchKernelGGL(k_mask, dim3(std::min(c->n_items, 2048)), dim3(NT), 0, c->stream, g, c->d_items, c->n_items, c->d_xy, c->d_mask);

@@ -1,0 +1,171 @@
+// eincm_binning.hip.h — device-side staging of a batch of event windows (eincm_set_windows).
+//
+// The loaders of the reference hand over events in time order (src/dataloaders/mvsec_loader.py:272-295); the engine wants them
+// binned by (window, 32x32 source tile) and cut into segments.  This is a counting sort done on the GPU:
+//   k_bin_hist     per 4096-event block: validate + per-tile histogram in LDS            -> blockhist (nblk, ntiles)
+//   k_bin_scan     per (window, tile): exclusive prefix over that window's blocks         -> blockoff in place, tilecount
+//   k_bin_tilescan one workgroup: exclusive scans of tile counts and of segment counts    -> tilebase, itembase, n_items
+//   k_bin_scatter  per block: position = tilebase + blockoff + LDS rank                   -> ev_xy, ev_t (binned)
+//   k_items / k_seg_minmax                                                                -> segments with their time range
+// Blocks are taken in input order, so a tile's events stay time-ordered at 4096-event granularity (inside a block the
+// order is whatever the LDS atomics return).  Order only affects how tight a segment's time range — and hence its LDS
+// window — is; results do not depend on it beyond fp32 summation order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "eincm_kernels.hip.h"
+
+namespace eincm {
+
+constexpr int BIN_CHUNK = 4096;
+constexpr int BIN_MAX_TILES = 12288;     // LDS histogram capacity (48 KiB); larger sensors use the host path
+
+struct BinBlock { int32_t win, start, count, first_blk; };    // start: global index of the block's first event
+
+// err[0] = smallest global index of an event outside the sensor (INT_MAX if none); err[1] = same for non-finite t
+__global__ __launch_bounds__(NT) void k_bin_hist(Geom g, const BinBlock* __restrict__ blks, const int16_t* __restrict__ xs,
+                                                  const int16_t* __restrict__ ys, const double* __restrict__ ts,
+                                                  uint32_t* __restrict__ blockhist, int* __restrict__ err)
+{
+    extern __shared__ uint32_t hist[];
+    const BinBlock bb = blks[blockIdx.x];
+    for (int i = threadIdx.x; i < g.ntiles; i += NT) hist[i] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < bb.count; i += NT) {
+        const int e = bb.start + i;
+        const int x = xs[e], y = ys[e];
+        const double t = ts[e];
+        if (x < 0 || x >= g.W || y < 0 || y >= g.H) { atomicMin(&err[0], e); continue; }
+        if (!(t - t == 0.0)) { atomicMin(&err[1], e); continue; }
+        atomicAdd(&hist[(y / TS) * g.tilesX + (x / TS)], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = blockhist + (size_t)blockIdx.x * g.ntiles;
+    for (int i = threadIdx.x; i < g.ntiles; i += NT) out[i] = hist[i];
+}
+
+// thread per (window, tile); win_blk (B+1): first block of each window
+__global__ void k_bin_scan(Geom g, const int32_t* __restrict__ win_blk, uint32_t* __restrict__ blockhist, int32_t* __restrict__ tilecount)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.B * g.ntiles) return;
+    const int b = idx / g.ntiles, tile = idx % g.ntiles;
+    uint32_t run = 0;
+    for (int k = win_blk[b]; k < win_blk[b + 1]; ++k) {
+        uint32_t* p = blockhist + (size_t)k * g.ntiles + tile;
+        const uint32_t v = *p;
+        *p = run;
+        run += v;
+    }
+    tilecount[idx] = (int32_t)run;
+}
+
+// one workgroup of 1024 threads: tilebase = exclusive scan of tilecount, itembase = exclusive scan of ceil(count/seg)
+__global__ __launch_bounds__(1024) void k_bin_tilescan(int M, int seg, const int32_t* __restrict__ tilecount, int32_t* __restrict__ tilebase,
+                                                        int32_t* __restrict__ itembase, int32_t* __restrict__ totals /* [n_events, n_items] */)
+{
+    __shared__ int64_t sA[1024];
+    __shared__ int64_t sB[1024];
+    const int t = threadIdx.x;
+    const int per = (M + 1023) / 1024;
+    const int lo = min(t * per, M), hi = min(lo + per, M);
+    int64_t a = 0, b = 0;
+    for (int i = lo; i < hi; ++i) { const int c = tilecount[i]; a += c; b += (c + seg - 1) / seg; }
+    sA[t] = a; sB[t] = b;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
+        int64_t va = 0, vb = 0;
+        if (t >= off) { va = sA[t - off]; vb = sB[t - off]; }
+        __syncthreads();
+        sA[t] += va; sB[t] += vb;
+        __syncthreads();
+    }
+    int64_t ra = sA[t] - a, rb = sB[t] - b;               // exclusive prefix of this thread's chunk
+    for (int i = lo; i < hi; ++i) {
+        const int c = tilecount[i];
+        tilebase[i] = (int32_t)ra; itembase[i] = (int32_t)rb;
+        ra += c; rb += (c + seg - 1) / seg;
+    }
+    if (t == 1023) { totals[0] = (int32_t)sA[1023]; totals[1] = (int32_t)sB[1023]; }
+}
+
+__global__ __launch_bounds__(NT) void k_bin_scatter(Geom g, const BinBlock* __restrict__ blks, const int16_t* __restrict__ xs,
+                                                     const int16_t* __restrict__ ys, const double* __restrict__ ts,
+                                                     const uint32_t* __restrict__ blockoff, const int32_t* __restrict__ tilebase,
+                                                     uint32_t* __restrict__ ev_xy, double* __restrict__ ev_t)
+{
+    extern __shared__ uint32_t cnt[];
+    const BinBlock bb = blks[blockIdx.x];
+    for (int i = threadIdx.x; i < g.ntiles; i += NT) cnt[i] = 0u;
+    __syncthreads();
+    const uint32_t* off = blockoff + (size_t)blockIdx.x * g.ntiles;
+    const int32_t* tb = tilebase + (size_t)bb.win * g.ntiles;
+    for (int i = threadIdx.x; i < bb.count; i += NT) {
+        const int e = bb.start + i;
+        const int x = xs[e], y = ys[e];
+        if (x < 0 || x >= g.W || y < 0 || y >= g.H) continue;      // already reported by k_bin_hist
+        const double t = ts[e];
+        if (!(t - t == 0.0)) continue;
+        const int tile = (y / TS) * g.tilesX + (x / TS);
+        const uint32_t r = atomicAdd(&cnt[tile], 1u);
+        const size_t pos = (size_t)tb[tile] + off[tile] + r;
+        ev_xy[pos] = (uint32_t)(uint16_t)x | ((uint32_t)(uint16_t)y << 16);
+        ev_t[pos] = t;
+    }
+}
+
+// thread per (window, tile): emit its segments
+__global__ void k_items(Geom g, int seg, const int32_t* __restrict__ tilecount, const int32_t* __restrict__ tilebase,
+                        const int32_t* __restrict__ itembase, Item* __restrict__ items)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.B * g.ntiles) return;
+    const int c = tilecount[idx], base = tilebase[idx];
+    int k = itembase[idx];
+    for (int s = 0; s < c; s += seg, ++k) {
+        Item it;
+        it.win = idx / g.ntiles; it.tile = idx % g.ntiles; it.begin = base + s; it.count = min(seg, c - s);
+        it.t_lo = 0.0; it.t_hi = 0.0;
+        items[k] = it;
+    }
+}
+
+// workgroup per segment (grid-stride): exact time range of its events
+__global__ __launch_bounds__(NT) void k_seg_minmax(int n_items, Item* __restrict__ items, const double* __restrict__ ev_t)
+{
+    __shared__ double smn[NWAVE], smx[NWAVE];
+    for (int k = blockIdx.x; k < n_items; k += gridDim.x) {
+        const int begin = items[k].begin, count = items[k].count;
+        double mn = INFINITY, mx = -INFINITY;
+        for (int i = threadIdx.x; i < count; i += NT) { const double t = ev_t[begin + i]; mn = fmin(mn, t); mx = fmax(mx, t); }
+        mn = wave_min(mn); mx = wave_max(mx);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < NWAVE; ++i) { mn = fmin(mn, smn[i]); mx = fmax(mx, smx[i]); }
+            items[k].t_lo = mn; items[k].t_hi = mx;
+        }
+    }
+}
+
+// edges (B,R,H,W) double -> float, and the fp64 moments of the STORED values: sum E, sum E^2 per (b, r).
+// grid (nblk, R, B); moments (B,R,2) zeroed beforehand.
+__global__ __launch_bounds__(NT) void k_edges(Geom g, const double* __restrict__ src, float* __restrict__ dst, double* __restrict__ moments)
+{
+    __shared__ double scratch[NWAVE];
+    const int r = blockIdx.y, b = blockIdx.z;
+    const size_t n = (size_t)g.H * g.W, base = ((size_t)b * g.R + r) * n;
+    double s = 0.0, ss = 0.0;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        const float f = (float)src[base + i];
+        dst[base + i] = f;
+        s += (double)f; ss += (double)f * (double)f;
+    }
+    s = block_sum(s, scratch);
+    ss = block_sum(ss, scratch);
+    if (threadIdx.x == 0) { atomicAdd(moments + ((size_t)b * g.R + r) * 2, s); atomicAdd(moments + ((size_t)b * g.R + r) * 2 + 1, ss); }
+}
+
+}  // namespace eincm

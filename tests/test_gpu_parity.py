@@ -301,6 +301,31 @@ def test_batch_equals_individual_windows():
         assert rel(g[b], g_ref) <= TOL
 
 
+def test_device_and_host_binning_agree(monkeypatch):
+    """eincm_set_windows bins events on the GPU (eincm_binning.hip.h); EINCM_HOST_BINNING=1 selects the host counting sort.
+    Same segments up to event order inside a tile -> same loss / gradient / IWE up to fp32 summation order."""
+    H, W, R = 150, 200, 3
+    wins = [synth.make_window(70 + i, (H, W), n, R, flow='smooth', flow_mag=12.0) for i, n in enumerate((40000, 9000, 1))]
+    ths = np.stack([synth.theta_near_truth(70 + i, w, (4, 4)) for i, w in enumerate(wins)])
+    p = engine.make_params(20.0, 35.0, 2.5e-4, 0.0, 0)
+    res = {}
+    for mode in ('device', 'host'):
+        if mode == 'host':
+            monkeypatch.setenv('EINCM_HOST_BINNING', '1')
+        else:
+            monkeypatch.delenv('EINCM_HOST_BINNING', raising=False)
+        with engine.Engine((H, W), 60000, max_refs=R, max_windows=3) as eng:
+            eng.set_windows([win_args(w) for w in wins])
+            v, g, _ = eng.loss_grad(ths, p)
+            res[mode] = (v, g, eng.iwes(), eng.zero_iwe())
+    monkeypatch.delenv('EINCM_HOST_BINNING', raising=False)
+    assert np.allclose(res['device'][0], res['host'][0], rtol=2e-6)
+    assert rel(res['device'][1], res['host'][1]) <= 2e-5
+    assert rel(res['device'][2], res['host'][2]) <= 2e-6 and rel(res['device'][3], res['host'][3]) <= 2e-6
+    v_ref, g_ref, _ = O.loss_and_grad(ths[0], *win_args(wins[0]), 20.0, 35.0, 2.5e-4, 0.0, 0, 5, (H, W))
+    assert abs(res['device'][0][0] - v_ref) <= TOL * abs(v_ref) and rel(res['device'][1][0], g_ref) <= TOL
+
+
 def test_handover():
     H, W, R = 100, 132, 3
     win = synth.make_window(50, (H, W), 20000, R, flow='smooth', flow_mag=10.0)
