@@ -60,6 +60,7 @@ SIGNATURES = [
     ('eincm_get_zero_iwe', C.c_int, [_P, C.POINTER(C.c_float)]),
     ('eincm_get_image_grad', C.c_int, [_P, C.POINTER(C.c_float)]),
     ('eincm_get_scaled_theta', C.c_int, [_P, _D]),
+    ('eincm_get_count_images', C.c_int, [_P, C.POINTER(C.c_uint32)]),
     ('eincm_multi_ref_weights', C.c_int, [C.c_int, _D]),
     ('eincm_resample_matrix', C.c_int, [C.c_int, C.c_int, C.c_int, _D]),
     ('eincm_get_timings', C.c_int, [_P, C.POINTER(Timings)]),

@@ -860,6 +860,25 @@ int eincm_get_scaled_theta(eincm_ctx* c, double* T) {
     return copy_out(c, T, c ? c->d_Theta : nullptr, c ? (size_t)c->g.B * c->g.H * c->g.W * 2 * sizeof(double) : 0);
 }
 
+int eincm_get_count_images(eincm_ctx* c, uint32_t* counts) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!counts) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (!c->staged || !c->have_eval) return fail(c, EINCM_ERR_STATE, "no evaluation yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    const Geom& g = c->g;
+    const size_t n = (size_t)g.B * g.R * g.H * g.W;
+    // the dL/dIWE buffer is free between evaluations and has exactly this many 4-byte cells
+    uint32_t* d = reinterpret_cast<uint32_t*>(c->d_G);
+    HIPCHK(c, hipMemsetAsync(d, 0, n * sizeof(uint32_t), c->stream));
+    if (c->n_items > 0)
+        hipLaunchKernelGGL(k_count, dim3(event_grid(c)), dim3(NT), 0, c->stream, g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta,
+                           c->d_edge_ts, d);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(counts, d, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EINCM_OK;
+}
+
 int eincm_get_timings(eincm_ctx* c, eincm_timings* t) {
     if (!c || !t) return EINCM_ERR_ARG;
     if (!(c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)))

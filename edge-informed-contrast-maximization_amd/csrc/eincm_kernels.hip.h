@@ -890,6 +890,34 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_count: integer image of the ROUNDED warped coordinates, counts[b,r,ry,rx] += 1 with the JAX index rule (the centre tap of
+// events_to_pdf_frame, event_utils.py:32-33,59).  Not on the evaluation path: it exposes the fp64 warp + half-to-even
+// rounding decisions as an integer image that must equal the oracle's bit for bit.  grid as k_splat (block_to_work).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_count(Geom g, int n_items, const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy,
+                                               const double* __restrict__ ev_t, const double* __restrict__ Theta,
+                                               const double* __restrict__ edge_ts, uint32_t* __restrict__ counts)
+{
+    int item, r;
+    if (!block_to_work(n_items, g.R, item, r)) return;
+    const Item it = items[item];
+    const double tau = edge_ts[it.win * g.R + r];
+    const double* __restrict__ Th = Theta + (size_t)it.win * g.H * g.W * 2;
+    uint32_t* __restrict__ img = counts + ((size_t)it.win * g.R + r) * g.H * g.W;
+    for (int i = threadIdx.x; i < it.count; i += NT) {
+        const uint32_t xy = ev_xy[it.begin + i];
+        const double dt = ev_t[it.begin + i] - tau;
+        const int x = xy & 0xffff, y = xy >> 16;
+        const double2 v = *reinterpret_cast<const double2*>(Th + ((size_t)y * g.W + x) * 2);
+        int irx, iry; float fx, fy;
+        warp_axis(x, v.x, dt, irx, fx);
+        warp_axis(y, v.y, dt, iry, fy);
+        const int gx = wrap_drop(irx, g.W), gy = wrap_drop(iry, g.H);
+        if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, 1u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_mask: event-presence mask (event_utils.py:64-76 / theta_utils.py:59-71).  grid-stride over events.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_mask(Geom g, const Item* __restrict__ items, int n_items, const uint32_t* __restrict__ ev_xy,

@@ -175,6 +175,12 @@ class Engine:
         self._check(self._lib.eincm_get_image_grad(self._ctx, a.ctypes.data_as(C.POINTER(C.c_float))))
         return a
 
+    def count_images(self):
+        """(B,R,H,W) uint32 histogram of the rounded warped coordinates under the last evaluation's Theta."""
+        a = np.empty((self.B, self.R, self.H, self.W), dtype=np.uint32)
+        self._check(self._lib.eincm_get_count_images(self._ctx, a.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return a
+
     def scaled_theta(self):
         a = np.empty((self.B, self.H, self.W, 2), dtype=np.float64)
         self._check(self._lib.eincm_get_scaled_theta(self._ctx, _dp(a)))

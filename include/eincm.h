@@ -157,6 +157,13 @@ int eincm_get_zero_iwe(eincm_ctx* ctx, float* zero_iwe);
 int eincm_get_image_grad(eincm_ctx* ctx, float* image_grad);
 int eincm_get_scaled_theta(eincm_ctx* ctx, double* scaled_theta);
 
+/* Integer image of the rounded warped coordinates under the Theta of the last evaluation:
+ * counts[b,r,ry,rx] = #{events of window b with round(warp(x,y,t; tau_r)) = (rx,ry)}, JAX wrap/drop index rule
+ * (the centre tap of events_to_pdf_frame, src/utils/event_utils.py:32-33,59).  counts (n_windows, n_refs, H, W) uint32.
+ * The IWE is a float image; this is its integer skeleton and must equal the reference's bit for bit.
+ * Overwrites the dL/dIWE image of the last evaluation (eincm_get_image_grad must be called before it). */
+int eincm_get_count_images(eincm_ctx* ctx, uint32_t* counts);
+
 /* compute_weights_for_multi_reference (losses.py:39-46) */
 int eincm_multi_ref_weights(int n_refs, double* w);
 

@@ -239,6 +239,16 @@ def events_to_pdf_frame(wx, wy, sensor_size):
     return frame.reshape(H, W)
 
 
+def rounded_count_image(wx, wy, sensor_size):
+    """Integer skeleton of events_to_pdf_frame: histogram of the rounded coordinates (event_utils.py:32-33) with the
+    scatter index rule of :59 (S1).  int64 (H, W)."""
+    H, W = sensor_size
+    cs, vx = _tap_index(_round_i(np.asarray(wx, dtype=np.float64)), 0, W)
+    rs, vy = _tap_index(_round_i(np.asarray(wy, dtype=np.float64)), 0, H)
+    v = vx & vy
+    return np.bincount(rs[v] * W + cs[v], minlength=H * W).reshape(H, W)
+
+
 def events_to_pdf_frame_adjoint(G, wx, wy):
     """Reverse-mode of events_to_pdf_frame w.r.t. (wx, wy) for an image cotangent G (round has zero derivative)."""
     H, W = G.shape

@@ -192,6 +192,33 @@ def test_full_size_permutation_and_shard_additivity(big_window):
         assert rel(iw[0] + iw[1], iw_full) <= 2e-6
 
 
+@pytest.mark.parametrize('shape', ['headline_2dof', 'headline_pyr16_bigflow', 'c3_dense'])
+def test_count_images_bit_exact_full_size(shape):
+    """Integer work is bit-exact: the histogram of ROUNDED warped coordinates (fp64 warp, half-to-even, JAX wrap/drop) equals
+    the oracle's at BASELINE sizes (10^6 events), every reference time, including events leaving the frame."""
+    if shape == 'c3_dense':
+        H, W, N, R = 480, 640, 1_000_000, 3
+        win = synth.make_window(81, (H, W), N, R, flow='smooth', flow_mag=30.0)
+        th = win['flow_gt'] * np.random.default_rng(1).uniform(0.5, 1.5, (H, W, 2))
+    else:
+        H, W, N, R = 260, 346, 1_000_000, 5
+        big = shape.endswith('bigflow')
+        win = synth.make_window(82, (H, W), N, R, flow='smooth' if big else 'constant', flow_mag=120.0 if big else 20.0)
+        th = synth.theta_near_truth(82, win, (16, 16) if big else (1, 1))
+    with engine.Engine((H, W), N, max_refs=R) as eng:
+        eng.set_window(*win_args(win))
+        eng.loss_grad(th, engine.make_params(20.0, 35.0, 0.0, 0.0, 1), want_grad=False)
+        cnt = eng.count_images()[0]
+    Theta = O.scale_theta_to_sensor_size(th, (H, W))
+    total = 0
+    for r in range(R):
+        wx, wy = O.per_pix_warp(Theta, win['xs'], win['ys'], win['ts'], win['edge_ts'][r])
+        ref = O.rounded_count_image(wx, wy, (H, W))
+        assert np.array_equal(cnt[r].astype(np.int64), ref), f'reference time {r}: {np.count_nonzero(cnt[r] != ref)} pixels differ'
+        total += int(ref.sum())
+    assert total <= N * R and (total < N * R) == (shape != 'headline_2dof' or total < N * R)
+
+
 def test_integer_shift_identity_full_size():
     """Constant integer displacement (theta = (k,0), all t - tau = 1): IWE = IUE shifted by -k columns (C.4 ii)."""
     H, W, N, k = 260, 346, 200000, 7
