@@ -13,6 +13,8 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_NONFINITE, ERR_UNSUPPORTED = 0, -1, -2, -3,
 CONTRAST_GRAD_MAG, CONTRAST_VARIANCE = 0, 1
 METHODS = {'linear': 0, 'bilinear': 0, 'triangle': 0, 'lanczos3': 1, 'lanczos5': 2, 'cubic': 3, 'bicubic': 3}
 PF_FULL_AUX = 1
+PF_NO_TV_GRAD = 2
+SW_DEFER_CONSTANTS = 1
 CF_TIMING = 1
 CF_TIMING_DOMINANT = 2
 
@@ -64,6 +66,13 @@ SIGNATURES = [
     ('eincm_multi_ref_weights', C.c_int, [C.c_int, _D]),
     ('eincm_resample_matrix', C.c_int, [C.c_int, C.c_int, C.c_int, _D]),
     ('eincm_get_timings', C.c_int, [_P, C.POINTER(Timings)]),
+    ('eincm_set_windows_ex', C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int16),
+                                       C.POINTER(C.c_int16), _D, _D, _D, C.c_uint32]),
+    ('eincm_forward_iwe', C.c_int, [_P, _D, C.c_int, C.c_int, C.POINTER(Params), C.c_int]),
+    ('eincm_finish_loss_grad', C.c_int, [_P, _D, _D, C.POINTER(Aux)]),
+    ('eincm_finish_constants', C.c_int, [_P]),
+    ('eincm_iwe_device_ptr', C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    ('eincm_mask_device_ptr', C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
 ]
 
 _lib = None

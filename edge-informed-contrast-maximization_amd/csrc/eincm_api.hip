@@ -103,6 +103,9 @@ struct eincm_ctx {
 
     // last eval bookkeeping
     bool have_eval = false;
+    // an evaluation split in two halves (eval_begin ... [caller may all-reduce the IWE stack] ... eval_end)
+    struct { bool active = false; EvalParams ep{}; int h = 0, w = 0; bool identity = false, want_grad = false, full_aux = false, div_grad = false; } pend;
+    bool constants_pending = false;   // staged with EINCM_SW_DEFER_CONSTANTS and not finished yet
 };
 
 namespace {
@@ -281,10 +284,6 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool want_grad, co
             hipLaunchKernelGGL(k_splat, dim3(event_grid(c)), dim3(NT), 2 * WIN_CAP * sizeof(float), c->stream, g, c->n_items,
                                c->chunk, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe);
     }
-    {
-        StageTimer t(c, EINCM_STAGE_STATS);
-        hipLaunchKernelGGL(k_stats, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_edges, c->d_parts);
-    }
     HIPCHK(c, hipGetLastError());
     return EINCM_OK;
 }
@@ -306,16 +305,15 @@ int collect_timings(eincm_ctx* c) {
     return EINCM_OK;
 }
 
-// The whole evaluation.  theta_host: (B,h,w,2) doubles (already validated).
-int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_params* p,
-             double* value, double* grad, eincm_aux* aux, bool for_constants) {
+// First half of an evaluation: theta -> Theta -> IWE stack (k_theta, k_splat).  theta_host: (B,h,w,2) doubles.
+int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_params* p, bool want_grad) {
     const Geom& g = c->g;
     const bool identity = (h == g.H && w == g.W);
     const size_t img = (size_t)g.H * g.W;
     const size_t nth = (size_t)h * w * 2;
-    const bool want_grad = (grad != nullptr);
     const bool full_aux = (p->flags & EINCM_PF_FULL_AUX) != 0;
     const bool div_grad = (p->delta != 0.0 && want_grad);
+    c->pend.active = false;
     if (div_grad && !c->d_gdiv) {      // rare path (the reference keeps delta = 0, configs/main.yaml:19): allocate lazily
         HIPCHK(c, dalloc(&c->d_gdiv, (size_t)c->maxB * c->maxR * img));
         HIPCHK(c, dalloc(&c->d_dgparts, (size_t)c->maxB * c->maxR * g.ntiles * 2));
@@ -337,11 +335,32 @@ int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_p
     ep.cur_pyr_lvl = p->cur_pyr_lvl; ep.contrast_kind = p->contrast_kind;
     ep.want_div = (full_aux || p->delta != 0.0) ? 1 : 0;
     ep.want_tv = ((p->cur_pyr_lvl <= 0) && (p->gamma != 0.0 || full_aux)) ? 1 : 0;
-    ep.use_tv_grad = (ep.want_tv && p->gamma != 0.0 && want_grad) ? 1 : 0;
+    ep.use_tv_grad = (ep.want_tv && p->gamma != 0.0 && want_grad && !(p->flags & EINCM_PF_NO_TV_GRAD)) ? 1 : 0;
     ep.h = h; ep.w = w; ep.identity = identity ? 1 : 0;
 
     int rc = launch_forward(c, h, w, identity, want_grad, theta_host);
     if (rc) return rc;
+    c->pend.active = true; c->pend.ep = ep; c->pend.h = h; c->pend.w = w; c->pend.identity = identity;
+    c->pend.want_grad = want_grad; c->pend.full_aux = full_aux; c->pend.div_grad = div_grad;
+    return EINCM_OK;
+}
+
+// Second half: image statistics, dL/dIWE, gather, projection, scalar assembly on whatever is in the IWE stack now.
+int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
+    if (!c->pend.active) return fail(c, EINCM_ERR_STATE, "no evaluation in flight");
+    c->pend.active = false;
+    const Geom& g = c->g;
+    const EvalParams ep = c->pend.ep;
+    const int h = c->pend.h, w = c->pend.w;
+    const bool identity = c->pend.identity, want_grad = c->pend.want_grad, full_aux = c->pend.full_aux, div_grad = c->pend.div_grad;
+    const size_t nth = (size_t)h * w * 2;
+    const bool timing = (c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)) != 0;
+    if (want_grad && !grad) return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
+    int rc = EINCM_OK;
+    {
+        StageTimer t(c, EINCM_STAGE_STATS);
+        hipLaunchKernelGGL(k_stats, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_edges, c->d_parts);
+    }
 
     if (ep.want_div) {
         hipLaunchKernelGGL(k_div, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_parts, c->d_divparts);
@@ -398,7 +417,6 @@ int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_p
     rc = collect_timings(c);
     if (rc) return rc;
     c->have_eval = true;
-    (void)for_constants;
 
     bool nonfinite = false;
     for (int b = 0; b < g.B; ++b) {
@@ -420,6 +438,43 @@ int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_p
             if (!std::isfinite(grad[i])) nonfinite = true;
     }
     if (nonfinite) return fail(c, EINCM_ERR_NONFINITE, "loss or gradient is not finite");
+    return EINCM_OK;
+}
+
+// The whole evaluation.  theta_host: (B,h,w,2) doubles (already validated).
+int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_params* p,
+             double* value, double* grad, eincm_aux* aux, bool /*for_constants*/) {
+    int rc = eval_begin(c, theta_host, h, w, p, grad != nullptr);
+    if (rc) return rc;
+    return eval_end(c, value, grad, aux);
+}
+
+// theta = 0 pass parameters used to obtain the window constants (every IWE_r then equals the IUE)
+eincm_params zero_pass_params() {
+    eincm_params p{};
+    p.alpha = 1.0; p.beta = 1.0; p.cur_pyr_lvl = 1; p.method = EINCM_METHOD_BILINEAR; p.flags = EINCM_PF_FULL_AUX;
+    return p;
+}
+
+// After the theta = 0 pass has been finished (eval_end): fill the window constants from its outputs.
+int store_constants(eincm_ctx* c) {
+    const Geom& g = c->g;
+    const size_t img = (size_t)g.H * g.W;
+    for (int b = 0; b < g.B; ++b) {
+        WinConst& wc = c->h_wc[b];
+        const OutScal& o = c->h_outs[b];
+        wc.c0_gradmag = o.contrast_gm[0];
+        wc.c0_var = o.var[0];
+        wc.d0 = o.div[0];
+        for (int r = 0; r < g.R; ++r) wc.zc[r] = o.corr[r];     // -MSE(E_r, n0)
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_wc, c->h_wc, (size_t)g.B * sizeof(WinConst), hipMemcpyHostToDevice, c->stream));
+    for (int b = 0; b < g.B; ++b)      // keep the IUE of every window (first reference image of the theta = 0 pass)
+        HIPCHK(c, hipMemcpyAsync(c->d_zero_iwe + (size_t)b * img, c->d_iwe + (size_t)b * g.R * img, img * sizeof(float),
+                                 hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_eval = false;
+    c->constants_pending = false;
     return EINCM_OK;
 }
 
@@ -548,8 +603,8 @@ void eincm_destroy(eincm_ctx* ctx) {
     delete ctx;
 }
 
-int eincm_set_windows(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* xs, const int16_t* ys,
-                      const double* ts, const double* edges, const double* edge_ts) {
+static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* xs, const int16_t* ys,
+                            const double* ts, const double* edges, const double* edge_ts, uint32_t sw_flags) {
     if (!c) return EINCM_ERR_ARG;
     if (n_windows < 1 || n_windows > c->maxB) return fail(c, EINCM_ERR_ARG, "n_windows %d outside 1..%d", n_windows, c->maxB);
     if (n_refs < 1 || n_refs > c->maxR) return fail(c, EINCM_ERR_ARG, "n_refs %d outside 1..%d", n_refs, c->maxR);
@@ -722,7 +777,7 @@ int eincm_set_windows(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_
     }
 
     // ---- zero-warp constants: one forward pass at theta = 0 (then IWE_r == IUE for every r) ----
-    // c0, zc[r], d0 are temporarily 1 so the pass is well defined; they are overwritten below.
+    // c0, zc[r], d0 are temporarily 1 so the pass is well defined; store_constants() overwrites them.
     for (int b = 0; b < n_windows; ++b) {
         WinConst& wc = c->h_wc[b];
         wc.c0_gradmag = 1.0; wc.c0_var = 1.0; wc.d0 = 1.0;
@@ -730,36 +785,94 @@ int eincm_set_windows(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_
     }
     HIPCHK(c, hipMemcpyAsync(c->d_wc, c->h_wc, (size_t)n_windows * sizeof(WinConst), hipMemcpyHostToDevice, c->stream));
     c->staged = true;
+    c->have_eval = false;
+    c->err.clear();
+    if (sw_flags & EINCM_SW_DEFER_CONSTANTS) {       // event-sharded mode: the caller sums the shards' IUEs first
+        c->constants_pending = true;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return EINCM_OK;
+    }
     {
         std::vector<double> zero((size_t)n_windows * 2, 0.0);
         std::vector<double> val((size_t)n_windows);
-        eincm_params p{};
-        p.alpha = 1.0; p.beta = 1.0; p.cur_pyr_lvl = 1; p.method = EINCM_METHOD_BILINEAR; p.flags = EINCM_PF_FULL_AUX;
+        const eincm_params p = zero_pass_params();
         const int rc = evaluate(c, zero.data(), 1, 1, &p, val.data(), nullptr, nullptr, true);
         if (rc != EINCM_OK && rc != EINCM_ERR_NONFINITE) { c->staged = false; return rc; }
     }
-    for (int b = 0; b < n_windows; ++b) {
-        WinConst& wc = c->h_wc[b];
-        const OutScal& o = c->h_outs[b];
-        wc.c0_gradmag = o.contrast_gm[0];
-        wc.c0_var = o.var[0];
-        wc.d0 = o.div[0];
-        for (int r = 0; r < n_refs; ++r) wc.zc[r] = o.corr[r];     // -MSE(E_r, n0)
-    }
-    HIPCHK(c, hipMemcpyAsync(c->d_wc, c->h_wc, (size_t)n_windows * sizeof(WinConst), hipMemcpyHostToDevice, c->stream));
-    // keep the IUE of every window (first reference image of the theta = 0 pass)
-    for (int b = 0; b < n_windows; ++b)
-        HIPCHK(c, hipMemcpyAsync(c->d_zero_iwe + (size_t)b * img, c->d_iwe + (size_t)b * n_refs * img, img * sizeof(float),
-                                 hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->have_eval = false;
+    const int rc = store_constants(c);
     c->err.clear();
+    return rc;
+}
+
+int eincm_set_windows(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* xs, const int16_t* ys,
+                      const double* ts, const double* edges, const double* edge_ts) {
+    return set_windows_impl(c, n_windows, n_refs, n_events, xs, ys, ts, edges, edge_ts, 0u);
+}
+
+int eincm_set_windows_ex(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* xs, const int16_t* ys,
+                         const double* ts, const double* edges, const double* edge_ts, uint32_t flags) {
+    return set_windows_impl(c, n_windows, n_refs, n_events, xs, ys, ts, edges, edge_ts, flags);
+}
+
+// ---- event-sharded evaluation: forward half / [caller all-reduces the IWE stack] / finishing half ----
+int eincm_forward_iwe(eincm_ctx* c, const double* theta, int h, int w, const eincm_params* p, int want_grad) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!c->staged) return fail(c, EINCM_ERR_STATE, "eincm_forward_iwe called before eincm_set_windows");
+    if (!p || h < 1 || w < 1) return fail(c, EINCM_ERR_ARG, "bad argument");
+    if (p->method < 0 || p->method > EINCM_METHOD_CUBIC) return fail(c, EINCM_ERR_ARG, "method %d unknown", p->method);
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<double> zero;
+    eincm_params pz;
+    if (!theta) {                                    // NULL theta = the theta = 0 pass that yields the window constants
+        zero.assign((size_t)c->g.B * 2, 0.0);
+        theta = zero.data(); h = 1; w = 1; pz = zero_pass_params(); p = &pz; want_grad = 0;
+    } else if (c->constants_pending) {
+        return fail(c, EINCM_ERR_STATE, "window constants pending: run eincm_forward_iwe(NULL theta), sum the IWE stacks, eincm_finish_constants");
+    }
+    int rc = eval_begin(c, theta, h, w, p, want_grad != 0);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // the IWE stack is complete: safe to reduce on any stream
+    return EINCM_OK;
+}
+
+int eincm_finish_loss_grad(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!value) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (c->constants_pending) return fail(c, EINCM_ERR_STATE, "window constants pending (eincm_finish_constants)");
+    HIPCHK(c, hipSetDevice(c->device));
+    return eval_end(c, value, grad, aux);
+}
+
+int eincm_finish_constants(eincm_ctx* c) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!c->constants_pending) return fail(c, EINCM_ERR_STATE, "no deferred window constants");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<double> val((size_t)c->g.B);
+    const int rc = eval_end(c, val.data(), nullptr, nullptr);
+    if (rc != EINCM_OK && rc != EINCM_ERR_NONFINITE) return rc;
+    const int rc2 = store_constants(c);
+    c->err.clear();
+    return rc2;
+}
+
+int eincm_iwe_device_ptr(eincm_ctx* c, void** dptr, int64_t* n_floats) {
+    if (!c || !dptr || !n_floats) return EINCM_ERR_ARG;
+    if (!c->staged) return fail(c, EINCM_ERR_STATE, "no staged windows");
+    *dptr = c->d_iwe; *n_floats = (int64_t)c->g.B * c->g.R * c->g.H * c->g.W;
+    return EINCM_OK;
+}
+
+int eincm_mask_device_ptr(eincm_ctx* c, void** dptr, int64_t* n_bytes) {
+    if (!c || !dptr || !n_bytes) return EINCM_ERR_ARG;
+    if (!c->staged) return fail(c, EINCM_ERR_STATE, "no staged windows");
+    *dptr = c->d_mask; *n_bytes = (int64_t)c->g.B * c->g.H * c->g.W;
     return EINCM_OK;
 }
 
 int eincm_loss_grad(eincm_ctx* c, const double* theta, int h, int w, const eincm_params* p, double* value, double* grad, eincm_aux* aux) {
     if (!c) return EINCM_ERR_ARG;
     if (!c->staged) return fail(c, EINCM_ERR_STATE, "eincm_loss_grad called before eincm_set_windows");
+    if (c->constants_pending) return fail(c, EINCM_ERR_STATE, "window constants pending (eincm_finish_constants)");
     if (!theta || !p || !value) return fail(c, EINCM_ERR_ARG, "null pointer argument");
     if (h < 1 || w < 1) return fail(c, EINCM_ERR_ARG, "theta shape (%d,%d,2) invalid", h, w);
     if (p->method < 0 || p->method > EINCM_METHOD_CUBIC) return fail(c, EINCM_ERR_ARG, "method %d unknown", p->method);

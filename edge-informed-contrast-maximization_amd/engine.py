@@ -78,8 +78,9 @@ class Engine:
         raise EincmError(rc, msg)
 
     # -- staging ----------------------------------------------------------------------------------
-    def set_windows(self, windows):
-        """windows: list of (xs, ys, ts, edges, edge_ts) tuples (the reference's datasample tuple)."""
+    def set_windows(self, windows, defer_constants=False):
+        """windows: list of (xs, ys, ts, edges, edge_ts) tuples (the reference's datasample tuple).
+        defer_constants: event-sharded mode (see sharding.ShardedEngine): stage only, finish with finish_constants()."""
         B = len(windows)
         R = len(np.atleast_1d(windows[0][4]))
         n = np.array([len(w[0]) for w in windows], dtype=np.int64)
@@ -94,9 +95,9 @@ class Engine:
             raise ValueError('every window needs the same number of reference times')
         if xs.size == 0:
             xs = np.zeros(1, np.int16); ys = np.zeros(1, np.int16); ts = np.zeros(1, np.float64)
-        rc = self._lib.eincm_set_windows(self._ctx, B, R, n.ctypes.data_as(C.POINTER(C.c_int64)),
-                                         xs.ctypes.data_as(C.POINTER(C.c_int16)), ys.ctypes.data_as(C.POINTER(C.c_int16)),
-                                         _dp(ts), _dp(edges), _dp(edge_ts))
+        rc = self._lib.eincm_set_windows_ex(self._ctx, B, R, n.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            xs.ctypes.data_as(C.POINTER(C.c_int16)), ys.ctypes.data_as(C.POINTER(C.c_int16)),
+                                            _dp(ts), _dp(edges), _dp(edge_ts), L.SW_DEFER_CONSTANTS if defer_constants else 0)
         self._check(rc)
         self.B, self.R = B, R
         self.n_events = n
@@ -123,6 +124,51 @@ class Engine:
         if want_aux:
             auxl = [{k: getattr(a, k) for k, _ in L.Aux._fields_} for a in aux]
         return value, grad, auxl
+
+    # -- the two halves of an evaluation (event-sharded mode) ------------------------------------------
+    def forward_iwe(self, theta, params, want_grad=True):
+        """k_theta + k_splat only; returns with the IWE stack complete in HBM.  theta=None: the theta = 0 constants pass."""
+        if theta is None:
+            rc = self._lib.eincm_forward_iwe(self._ctx, None, 1, 1, C.byref(make_params(1, 1, 0, 0, 1)), 0)
+            self._check(rc)
+            return None
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64))
+        if th.ndim == 3:
+            th = th[None]
+        if th.ndim != 4 or th.shape[0] != self.B or th.shape[3] != 2:
+            raise ValueError(f'theta must be ({self.B},h,w,2), got {th.shape}')
+        self._check(self._lib.eincm_forward_iwe(self._ctx, _dp(th), th.shape[1], th.shape[2], C.byref(params), 1 if want_grad else 0))
+        return th.shape
+
+    def finish_loss_grad(self, theta_shape, want_grad=True, want_aux=False, allow_nonfinite=True):
+        value = np.empty(self.B, dtype=np.float64)
+        grad = np.empty(theta_shape, dtype=np.float64) if want_grad else None
+        aux = (L.Aux * self.B)() if want_aux else None
+        rc = self._lib.eincm_finish_loss_grad(self._ctx, _dp(value), _dp(grad) if want_grad else None, aux)
+        self._check(rc, allow_nonfinite)
+        auxl = [{k: getattr(a, k) for k, _ in L.Aux._fields_} for a in aux] if want_aux else None
+        return value, grad, auxl
+
+    def finish_constants(self):
+        self._check(self._lib.eincm_finish_constants(self._ctx))
+
+    def _device_view(self, getter, typestr, itemsize, shape):
+        import torch
+        ptr, n = C.c_void_p(), C.c_int64()
+        self._check(getter(self._ctx, C.byref(ptr), C.byref(n)))
+
+        class _View:            # the CUDA array interface: a zero-copy torch tensor over the engine's HBM buffer
+            __cuda_array_interface__ = {'shape': shape, 'typestr': typestr, 'data': (int(ptr.value), False), 'version': 2,
+                                        'strides': None}
+        return torch.as_tensor(_View(), device=torch.device('cuda', torch.cuda.current_device()))
+
+    def iwe_tensor(self):
+        """torch view of the IWE stack (B,R,H,W) float32 in HBM, for an RCCL all-reduce between the two halves."""
+        return self._device_view(self._lib.eincm_iwe_device_ptr, '<f4', 4, (self.B, self.R, self.H, self.W))
+
+    def mask_tensor(self):
+        """torch view of the event-presence mask (B,H,W) uint8."""
+        return self._device_view(self._lib.eincm_mask_device_ptr, '|u1', 1, (self.B, self.H, self.W))
 
     def handover_loss_grad(self, alpha_handover, prev_theta, theta, params, want_grad=True, allow_nonfinite=True):
         pt = np.ascontiguousarray(np.asarray(prev_theta, dtype=np.float64))

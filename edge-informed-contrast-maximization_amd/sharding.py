@@ -1,4 +1,4 @@
-"""Multi-GPU decomposition of the EINCM path: independent event windows shard across ranks (one process per GPU);
+"""Multi-GPU decomposition of the EINCM path.  Mode 1 (bench, BASELINE C4): independent event windows shard across ranks (one process per GPU);
 the only exchange is the all-reduce of the scalar batch loss (RCCL over xGMI when the tensor is on a GPU, gloo on CPU).
 
 The reference is single-process / single-device (no collective anywhere); windows are independent
@@ -49,3 +49,75 @@ def gather_window_losses(local_values, n_windows, rank, world_size, device=None)
         idx = shard_windows(n_windows, r, world_size)
         res[idx.start:idx.stop] = o.cpu().numpy()[:len(idx)]
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mode 2 (BASELINE C5): ONE window (or batch) whose EVENTS are split over the ranks.
+# ---------------------------------------------------------------------------------------------------------------------
+def shard_events(n_events, rank, world_size):
+    """Contiguous (in time) slice of event indices owned by ``rank``."""
+    return shard_windows(n_events, rank, world_size)
+
+
+class ShardedEngine:
+    """Event-sharded evaluation: every rank stages ITS slice of each window's events (edges replicated) in its own Engine.
+    The IWE is additive over events (src/utils/event_utils.py:59 is a pure sum), so one exchange step suffices per
+    evaluation: all-reduce(sum) of the (B,R,H,W) fp32 IWE stack between k_splat and k_stats (0.36 MB x R at 260x346,
+    1.2 MB x R at 480x640), then every rank finishes on the summed stack and the small (h,w,2) gradients are summed.
+    The loss is identical on every rank.  Collectives go through torch.distributed's default group: backend 'nccl'
+    (= RCCL over xGMI) reduces the engine's HBM buffer in place; 'gloo' (CPU rehearsal) bounces through host memory.
+    """
+
+    def __init__(self, engine, rank=None, world_size=None):
+        import torch.distributed as dist
+        self.eng = engine
+        self.dist = dist
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.rank = dist.get_rank() if self.on else 0
+        self.world = dist.get_world_size() if self.on else 1
+        self.gpu_collectives = self.on and dist.get_backend() == 'nccl'
+
+    def _allreduce_(self, t, op):
+        import torch
+        if not self.on:
+            return
+        if self.gpu_collectives:
+            self.dist.all_reduce(t, op=op)
+            torch.cuda.current_stream().synchronize()
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=op)
+            t.copy_(h)
+            torch.cuda.current_stream().synchronize()
+
+    def set_windows(self, local_windows):
+        """local_windows: this rank's (xs, ys, ts, edges, edge_ts) per window — its slice of the events, the full edges."""
+        D = self.dist
+        self.eng.set_windows(local_windows, defer_constants=True)
+        self._allreduce_(self.eng.mask_tensor(), D.ReduceOp.MAX)          # TV needs the global event mask
+        self.eng.forward_iwe(None, None)                                   # theta = 0: partial IUE of this shard
+        self._allreduce_(self.eng.iwe_tensor(), D.ReduceOp.SUM)
+        self.eng.finish_constants()
+
+    def loss_grad(self, theta, params, want_grad=True):
+        """(value (B,), grad (B,h,w,2) | None): value identical on every rank, grad summed over ranks."""
+        import copy
+        import torch
+        D = self.dist
+        p = params
+        if self.rank != 0:                                                  # the replicated TV gradient counts once
+            from . import _lib as L
+            p = copy.copy(params)
+            p.flags = params.flags | L.PF_NO_TV_GRAD
+        shape = self.eng.forward_iwe(theta, p, want_grad=want_grad)
+        self._allreduce_(self.eng.iwe_tensor(), D.ReduceOp.SUM)
+        v, g, _ = self.eng.finish_loss_grad(shape, want_grad=want_grad)
+        if want_grad and self.on:
+            t = torch.from_numpy(g)
+            if self.gpu_collectives:
+                t = t.cuda()
+                D.all_reduce(t, op=D.ReduceOp.SUM)
+                g = t.cpu().numpy()
+            else:
+                D.all_reduce(t, op=D.ReduceOp.SUM)
+        return v, g

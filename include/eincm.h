@@ -44,6 +44,8 @@ extern "C" {
 #define EINCM_METHOD_CUBIC    3    /* 'cubic' / 'bicubic' */
 
 /* eincm_params.flags */
+#define EINCM_PF_NO_TV_GRAD 2u     /* leave the TV term out of the gradient (its value stays in the loss): event-sharded
+                                      evaluation adds the replicated TV gradient on one shard only */
 #define EINCM_PF_FULL_AUX   1u     /* also evaluate the report-only terms: IWE divergence (losses.py:79-81),
                                       TV at any gamma (losses.py:75), FWL (losses.py:84) */
 
@@ -134,6 +136,13 @@ int eincm_set_windows(eincm_ctx* ctx, int n_windows, int n_refs, const int64_t* 
                       const int16_t* xs, const int16_t* ys, const double* ts,
                       const double* edges, const double* edge_ts);
 
+/* eincm_set_windows with flags.  EINCM_SW_DEFER_CONSTANTS: stage only; the zero-warp constants are finished later by
+ * eincm_forward_iwe(theta = NULL) -> [sum the IWE stacks of all shards] -> eincm_finish_constants (event-sharded mode). */
+#define EINCM_SW_DEFER_CONSTANTS 1u
+int eincm_set_windows_ex(eincm_ctx* ctx, int n_windows, int n_refs, const int64_t* n_events,
+                         const int16_t* xs, const int16_t* ys, const double* ts,
+                         const double* edges, const double* edge_ts, uint32_t flags);
+
 /* value_and_grad(loss_func) for every staged window (losses.py:108-205 + its reverse pass).
  *   theta  (n_windows, h, w, 2)     value (n_windows)     grad (n_windows, h, w, 2) or NULL (forward only)
  *   aux    (n_windows) or NULL                                                                         */
@@ -171,6 +180,20 @@ int eincm_multi_ref_weights(int n_refs, double* w);
 int eincm_resample_matrix(int n_in, int n_out, int method, double* A);
 
 int eincm_get_timings(eincm_ctx* ctx, eincm_timings* t);
+
+/* Event-sharded evaluation: the events of the SAME windows are split over several contexts (one per GPU);
+ * edges and edge_ts are replicated.  The IWE is additive over events (src/utils/event_utils.py:59 is a pure sum), so
+ *   every shard:  eincm_forward_iwe(theta)            k_theta + k_splat on its own events; returns stream-synchronised
+ *   caller:       all-reduce(sum) of the IWE stacks   (RCCL on eincm_iwe_device_ptr; (n_windows, n_refs, H, W) float)
+ *   every shard:  eincm_finish_loss_grad              statistics ... gradient on the summed stack
+ * gives the same value on every shard and gradients that SUM to the full gradient (pass EINCM_PF_NO_TV_GRAD on all but
+ * one shard).  Staging: eincm_set_windows_ex(..., EINCM_SW_DEFER_CONSTANTS), all-reduce(max) of the event masks
+ * (eincm_mask_device_ptr, uint8), eincm_forward_iwe(theta = NULL), all-reduce(sum) of the IWE stacks, eincm_finish_constants. */
+int eincm_forward_iwe(eincm_ctx* ctx, const double* theta, int h, int w, const eincm_params* p, int want_grad);
+int eincm_finish_loss_grad(eincm_ctx* ctx, double* value, double* grad, eincm_aux* aux);
+int eincm_finish_constants(eincm_ctx* ctx);
+int eincm_iwe_device_ptr(eincm_ctx* ctx, void** dptr, int64_t* n_floats);
+int eincm_mask_device_ptr(eincm_ctx* ctx, void** dptr, int64_t* n_bytes);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,101 @@
+"""Event-sharded evaluation (second mode): the events of one window split over ranks, IWE all-reduced between
+the two halves of the evaluation.  On the single-GPU box two ranks share GPU 0 and use gloo (the collective bounces through
+host memory); on a real node the same code runs with backend 'nccl' (RCCL) on the HBM buffer in place."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+H, W, N, R = 120, 160, 40000, 3
+CASES = [((1, 1), 0.0, 4), ((4, 4), 2.5e-4, 0), ('dense', 2.5e-4, 0)]
+
+
+def _inputs():
+    synth = importlib.import_module('edge-informed-contrast-maximization_amd.synth')
+    win = synth.make_window(33, (H, W), N, R, flow='smooth', flow_mag=10.0)
+    thetas = []
+    for hw, _, _ in CASES:
+        thetas.append(win['flow_gt'] * 0.9 if hw == 'dense' else synth.theta_near_truth(33, win, hw))
+    return win, thetas
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    engine = importlib.import_module('edge-informed-contrast-maximization_amd.engine')
+    sh = importlib.import_module('edge-informed-contrast-maximization_amd.sharding')
+    win, thetas = _inputs()
+    mine = sh.shard_events(N, rank, world)
+    sl = slice(mine.start, mine.stop)
+    with engine.Engine((H, W), N, max_refs=R) as eng:
+        se = sh.ShardedEngine(eng)
+        se.set_windows([(win['xs'][sl], win['ys'][sl], win['ts'][sl], win['edges'], win['edge_ts'])])
+        out = []
+        for th, (hw, gamma, lvl) in zip(thetas, CASES):
+            v, g = se.loss_grad(th, engine.make_params(20.0, 35.0, gamma, 0.0, lvl))
+            out.append((float(v[0]), g[0].copy()))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world1_sharded_engine_equals_engine(built_lib):
+    engine = importlib.import_module('edge-informed-contrast-maximization_amd.engine')
+    sh = importlib.import_module('edge-informed-contrast-maximization_amd.sharding')
+    win, thetas = _inputs()
+    a = (win['xs'], win['ys'], win['ts'], win['edges'], win['edge_ts'])
+    with engine.Engine((H, W), N, max_refs=R) as e1, engine.Engine((H, W), N, max_refs=R) as e2:
+        e1.set_window(*a)
+        se = sh.ShardedEngine(e2)
+        se.set_windows([a])
+        assert tuple(e2.iwe_tensor().shape) == (1, R, H, W) and e2.mask_tensor().sum().item() == np.count_nonzero(
+            np.bincount(win['ys'].astype(int) * W + win['xs'].astype(int), minlength=H * W))
+        for th, (hw, gamma, lvl) in zip(thetas, CASES):
+            p = engine.make_params(20.0, 35.0, gamma, 0.0, lvl)
+            v1, g1, _ = e1.loss_grad(th, p)
+            v2, g2 = se.loss_grad(th, p)
+            assert v2[0] == pytest.approx(v1[0], rel=2e-6)
+            assert np.abs(g2 - g1).max() <= 2e-5 * np.abs(g1).max()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_split_events_match_unsharded(built_lib):
+    from oracle import eincm_oracle as O
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    win, thetas = _inputs()
+    a = (win['xs'], win['ys'], win['ts'], win['edges'], win['edge_ts'])
+    for i, (th, (hw, gamma, lvl)) in enumerate(zip(thetas, CASES)):
+        v_ref, g_ref, _ = O.loss_and_grad(th, *a, 20.0, 35.0, gamma, 0.0, lvl, 5, (H, W))
+        for r in range(world):
+            v, g = res[r][i]
+            assert abs(v - v_ref) <= 1e-5 * abs(v_ref), (hw, r)
+            assert np.abs(g - g_ref).max() <= 1e-5 * np.abs(g_ref).max(), (hw, r)     # already summed over ranks
+        assert res[0][i][0] == pytest.approx(res[1][i][0], rel=1e-12)                  # identical loss on every rank
