@@ -219,6 +219,28 @@ def test_count_images_bit_exact_full_size(shape):
     assert total <= N * R and (total < N * R) == (shape != 'headline_2dof' or total < N * R)
 
 
+def test_c5_shape_ten_million_events():
+    """BASELINE C5 shape: 480x640, 10^7 events, R = 3, 16x16 theta.  The oracle's float path is too slow for a test at this
+    size; its integer skeleton is not: rounded-coordinate count images must match bit for bit, the theta = 0 pass must
+    reproduce the IUE at every reference time, and the gradient must be finite."""
+    H, W, N, R = 480, 640, 10_000_000, 3
+    win = synth.make_window(91, (H, W), N, R, flow='smooth', flow_mag=30.0)
+    th = synth.theta_near_truth(91, win, (16, 16))
+    with engine.Engine((H, W), N, max_refs=R) as eng:
+        eng.set_window(*win_args(win))
+        v0, _, _ = eng.loss_grad(np.zeros((1, 1, 2)), engine.make_params(2000.0, 4000.0, 0.0, 0.0, 4), want_grad=False)
+        assert v0[0] == pytest.approx(-(2000.0 + 4000.0) / R, rel=TOL)
+        iw, z = eng.iwes()[0], eng.zero_iwe()[0]
+        assert all(rel(iw[r], z) <= 2e-6 for r in range(R))
+        v, g, _ = eng.loss_grad(th, engine.make_params(2000.0, 4000.0, 2.5e-4, 0.0, 0))
+        assert np.isfinite(v[0]) and np.all(np.isfinite(g)) and np.abs(g).max() > 0
+        cnt = eng.count_images()[0]
+    Theta = O.scale_theta_to_sensor_size(th, (H, W))
+    for r in range(R):
+        wx, wy = O.per_pix_warp(Theta, win['xs'], win['ys'], win['ts'], win['edge_ts'][r])
+        assert np.array_equal(cnt[r].astype(np.int64), O.rounded_count_image(wx, wy, (H, W)))
+
+
 def test_integer_shift_identity_full_size():
     """Constant integer displacement (theta = (k,0), all t - tau = 1): IWE = IUE shifted by -k columns (C.4 ii)."""
     H, W, N, k = 260, 346, 200000, 7

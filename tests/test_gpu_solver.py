@@ -97,3 +97,15 @@ def test_second_window_uses_handover():
     for k in (0, 1):
         assert 0.0 <= o2['final_handover_weight_pyr'][f'pyr_lvl_{k}'] <= 1.0
     assert np.abs(o2['final_theta_pyr']['pyr_lvl_2'][0, 0] - w2['flow_gt'][0, 0]).max() < 1.0
+
+
+def test_example_sequence_script_runs():
+    """examples/run_sequence.py (SOLVE + EVAL over a window sequence with the reference's defaults) end to end."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'examples', 'run_sequence.py'), '--windows', '2'], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'window 1:' in r.stdout and 'solved handover weights' in r.stdout and 'mean FWL' in r.stdout
