@@ -370,6 +370,7 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
         hipLaunchKernelGGL(k_tv, dim3(g.ntiles, g.B), dim3(NT), 0, c->stream, g, c->d_Theta, c->d_mask, c->d_tvg,
                            c->d_tvparts, full_aux ? 1 : 0);
     }
+    const bool direct11 = want_grad && !identity && h == 1 && w == 1;
     if (want_grad) {
         {
             StageTimer t(c, EINCM_STAGE_IMGRAD);
@@ -383,13 +384,16 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
             StageTimer t(c, EINCM_STAGE_GATHER);
             if (c->n_items > 0)
                 hipLaunchKernelGGL(k_gather, dim3(event_grid(c)), dim3(NT), WIN_CAP * sizeof(float) + TS * TS * 2 * sizeof(double), c->stream,
-                               g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta);
+                               g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta,
+                               direct11 ? 1 : 0, c->d_gth, (int)c->coarse_cap);
         }
-        if (!identity) {
+        // accumulators: two halves (event gradient | TV gradient), each (maxB, coarse_cap), zeroed by k_theta.
+        // 2-DoF theta: k_gather already summed the event gradient into the first half; only the TV image needs projecting.
+        const int nsrc = (direct11 ? 0 : 1) + (ep.use_tv_grad ? 1 : 0);
+        if (!identity && nsrc > 0) {
             StageTimer t(c, EINCM_STAGE_PROJECT);
-            // accumulators: two halves (event gradient | TV gradient), each (maxB, coarse_cap), zeroed by k_theta
-            hipLaunchKernelGGL(k_project, dim3(g.ntiles, g.B, ep.use_tv_grad ? 2 : 1), dim3(NT), 0, c->stream, g, h, w,
-                               (int)c->coarse_cap, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_gTheta, c->d_tvg, c->d_gth,
+            hipLaunchKernelGGL(k_project, dim3(g.ntiles, g.B, nsrc), dim3(NT), 0, c->stream, g, h, w,
+                               (int)c->coarse_cap, direct11 ? 1 : 0, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_gTheta, c->d_tvg, c->d_gth,
                                c->d_gth + (size_t)c->maxB * c->coarse_cap);
         }
     }

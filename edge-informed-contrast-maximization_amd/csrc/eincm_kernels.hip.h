@@ -774,10 +774,13 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
         const double* __restrict__ Theta, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
         const float* __restrict__ G,           // (B,R,H,W)
-        float* __restrict__ gTheta)            // (B,H,W,2), zeroed
+        float* __restrict__ gTheta,            // (B,H,W,2), zeroed
+        int direct11, double* __restrict__ gth_main, int gth_cap)   // 2-DoF theta: sum straight into dL/dtheta (B,gth_cap)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double red11[NWAVE];
     double* accum = reinterpret_cast<double*>(lds + WIN_CAP);   // TS*TS*2 doubles (ds_add_f64 is ~10x ds_add_f32 on gfx950)
+    double sum11x = 0.0, sum11y = 0.0;          // direct11: this thread's share of sum_e -dt * dL/dw
     int item, r;
     if (!block_to_work(n_items, g.R, item, r)) return;
     const Item it = items[item];
@@ -792,7 +795,8 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
             lds[row * wn.ww + col] = (gx >= 0 && gy >= 0) ? Gi[(size_t)gy * g.W + gx] : 0.0f;
         }
     }
-    for (int i = threadIdx.x; i < TS * TS * 2; i += NT) accum[i] = 0.0;
+    if (!direct11)
+        for (int i = threadIdx.x; i < TS * TS * 2; i += NT) accum[i] = 0.0;
     __syncthreads();
 
     const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
@@ -858,9 +862,13 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
             gwx += cs * kx[dx] * qx;
             gwy += csq * kx[dx];
         }
-        double* a = accum + ((y - y0) * TS + (x - x0)) * 2;
-        atomicAdd(a, -dt * (double)gwx);
-        atomicAdd(a + 1, -dt * (double)gwy);
+        if (direct11) {          // theta (1,1,2): Theta is constant, dL/dtheta = sum over all events; no per-pixel image needed
+            sum11x -= dt * (double)gwx; sum11y -= dt * (double)gwy;
+        } else {
+            double* a = accum + ((y - y0) * TS + (x - x0)) * 2;
+            atomicAdd(a, -dt * (double)gwx);
+            atomicAdd(a + 1, -dt * (double)gwy);
+        }
     };
     // three-stage pipeline with renamed register sets, as in k_splat
     auto step = [&](EvReg& cur, EvReg& mid, EvReg& nxt, int j) {
@@ -878,6 +886,15 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         step(A, B, C, j);
         if (j + 1 < iters) step(B, C, A, j + 1);
         if (j + 2 < iters) step(C, A, B, j + 2);
+    }
+    if (direct11) {
+        sum11x = block_sum(sum11x, red11);
+        sum11y = block_sum(sum11y, red11);
+        if (threadIdx.x == 0) {
+            if (sum11x != 0.0) atomicAdd(gth_main + (size_t)it.win * gth_cap, sum11x);
+            if (sum11y != 0.0) atomicAdd(gth_main + (size_t)it.win * gth_cap + 1, sum11y);
+        }
+        return;
     }
     __syncthreads();
     float* __restrict__ gT = gTheta + (size_t)it.win * g.H * g.W * 2;
@@ -1062,7 +1079,7 @@ __global__ __launch_bounds__(NT) void k_tv(Geom g, const double* __restrict__ Th
 // into LDS cell accumulators (ds_add_f64), flushed with global_atomic_add_f64.  More cells than PROJ_CELLS: straight to HBM.
 // ------------------------------------------------------------------------------------------------
 constexpr int PROJ_CELLS = 1024;
-__global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap,
+__global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, int src0,
         const double* __restrict__ AH, const double* __restrict__ AW,
         const int2* __restrict__ rowtap, const int2* __restrict__ coltap,
         const float* __restrict__ gTheta, const double* __restrict__ tvg,
@@ -1071,7 +1088,7 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap,
     __shared__ double scratch[NWAVE];
     __shared__ int rng[4];
     __shared__ double cells[PROJ_CELLS * 2];
-    const int tile = blockIdx.x, b = blockIdx.y, src = blockIdx.z;
+    const int tile = blockIdx.x, b = blockIdx.y, src = blockIdx.z + src0;
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
     const int x1 = min(x0 + TS, g.W), y1 = min(y0 + TS, g.H);
