@@ -54,7 +54,10 @@ struct eincm_ctx {
     // device buffers
     uint32_t* d_xy = nullptr;      // (maxN) x | y<<16, binned
     double* d_t = nullptr;         // (maxN)
-    Item* d_items = nullptr;       // (max_items)
+    Item* d_items = nullptr;       // (max_items) segments walked by k_gather / k_count / k_mask
+    Item* d_items_s = nullptr;     // (max_items) shorter segments walked by k_splat
+    int n_items_s = 0; int seg_s = 0; int seg_s_used = 0;
+    int wincap = WIN_CAP_DEFAULT;
     // device-side staging (eincm_binning.hip.h)
     int16_t* d_raw_x = nullptr; int16_t* d_raw_y = nullptr; double* d_raw_t = nullptr;   // (maxN) events as handed over
     BinBlock* d_binblocks = nullptr; int32_t* d_win_blk = nullptr; uint32_t* d_blockhist = nullptr;
@@ -191,7 +194,7 @@ void multi_ref_weights(int R, double* w) {
 
 void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
+    F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_items_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
     F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
     F(c->d_divparts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
@@ -256,6 +259,7 @@ int ensure_resample(eincm_ctx* c, int h, int w, int method) {
 
 // blocks of the two event kernels: every (segment, reference time) pair, padded to a multiple of 8 segments (block_to_work)
 unsigned event_grid(const eincm_ctx* c) { return (unsigned)(((c->n_items + NXCD - 1) / NXCD) * NXCD * c->g.R); }
+unsigned splat_grid(const eincm_ctx* c) { return (unsigned)(((c->n_items_s + NXCD - 1) / NXCD) * NXCD * c->g.R); }
 
 // Launch the forward half: theta -> Theta -> IWE stack -> image statistics.
 // theta must already be in d_theta_in (identity: (B,H,W,2); else (B,h,w,2)).
@@ -280,9 +284,9 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool want_grad, co
     }
     {
         StageTimer t(c, EINCM_STAGE_SPLAT);
-        if (c->n_items > 0)
-            hipLaunchKernelGGL(k_splat, dim3(event_grid(c)), dim3(NT), 2 * WIN_CAP * sizeof(float), c->stream, g, c->n_items,
-                               c->chunk, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe);
+        if (c->n_items_s > 0)
+            hipLaunchKernelGGL(k_splat, dim3(splat_grid(c)), dim3(NT), 2 * g.wincap * sizeof(float), c->stream, g, c->n_items_s,
+                               c->chunk, c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe);
     }
     HIPCHK(c, hipGetLastError());
     return EINCM_OK;
@@ -383,7 +387,7 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
         {
             StageTimer t(c, EINCM_STAGE_GATHER);
             if (c->n_items > 0)
-                hipLaunchKernelGGL(k_gather, dim3(event_grid(c)), dim3(NT), WIN_CAP * sizeof(float) + TS * TS * 2 * sizeof(double), c->stream,
+                hipLaunchKernelGGL(k_gather, dim3(event_grid(c)), dim3(NT), g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double)), c->stream,
                                g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta,
                                direct11 ? 1 : 0, c->d_gth, (int)c->coarse_cap);
         }
@@ -530,6 +534,8 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     c->cflags = flags;
     if (const char* s = getenv("EINCM_CHUNK")) { int v = atoi(s); if (v >= NT && v <= MAX_CHUNK) c->chunk = (v / NT) * NT; }
     if (const char* s = getenv("EINCM_SEG")) { int v = atoi(s); if (v >= 64 && v <= MAX_SEG) c->seg = v; }
+    if (const char* s = getenv("EINCM_SEG_SPLAT")) { int v = atoi(s); if (v >= 64 && v <= MAX_SEG) c->seg_s = v; }
+    if (const char* s = getenv("EINCM_WINCAP")) { int v = atoi(s); if (v >= 1024 && v <= WIN_CAP_MAX) c->wincap = v; }
     auto bail = [&](const char* what, hipError_t err) -> eincm_ctx* {
         fail(nullptr, EINCM_ERR_HIP, "eincm_create: %s failed: %s", what, hipGetErrorString(err));
         free_all(c);
@@ -546,6 +552,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_xy, (size_t)max_events_total));
     TRY(dalloc(&c->d_t, (size_t)max_events_total));
     TRY(dalloc(&c->d_items, (size_t)c->max_items));
+    TRY(dalloc(&c->d_items_s, (size_t)c->max_items));
     c->host_binning = (ntiles > BIN_MAX_TILES) || (getenv("EINCM_HOST_BINNING") != nullptr);
     if (!c->host_binning) {
         c->max_binblocks = max_events_total / BIN_CHUNK + (int64_t)B + 1;
@@ -625,15 +632,16 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     Geom g{};
     g.H = H; g.W = W; g.R = n_refs; g.B = n_windows;
     g.tilesX = (W + TS - 1) / TS; g.tilesY = (H + TS - 1) / TS; g.ntiles = g.tilesX * g.tilesY;
+    g.wincap = c->wincap; g.winmaxw = std::max(40, (int)std::lround(std::sqrt((double)c->wincap * 1.4)));
 
-    // Segment length: long enough that one window flush is amortised over many events, short enough that the two
-    // event kernels still launch >= ~2048 workgroups (8 per CU) when the batch is small.
-    int seg = c->seg;
-    if (seg <= 0) {
-        const int64_t per = (N * (int64_t)n_refs + 2047) / 2048;
-        seg = (int)std::min<int64_t>(16384, std::max<int64_t>(256, ((per + 255) / 256) * 256));
-    }
+    // Segment lengths (events per workgroup and reference time).  Measured on MI355X (tools/dev_tune.sh, tools/dev_tune1.py):
+    // per-workgroup fixed cost (window clear / flush, G-window load, reductions) dominates short segments at every batch size,
+    // so segments are long even when that leaves < 1 workgroup per CU; k_splat, bound by LDS atomics, prefers somewhat
+    // shorter ones (more, smaller windows) than k_gather, which pays a G-window load per segment.
+    int seg = c->seg > 0 ? c->seg : 8192;
     c->seg_used = seg;
+    int seg_s = c->seg_s > 0 ? c->seg_s : 4096;
+    c->seg_s_used = seg_s;
     const size_t img = (size_t)H * W;
     for (int b = 0; b < n_windows; ++b) {
         memset(&c->h_wc[b], 0, sizeof(WinConst));
@@ -641,7 +649,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         for (int r = 0; r < n_refs; ++r)
             if (!std::isfinite(edge_ts[b * n_refs + r])) return fail(c, EINCM_ERR_ARG, "edge_ts[%d,%d] is not finite", b, r);
     }
-    int n_items_total = 0;
+    int n_items_total = 0, n_items_s_total = 0;
     if (!c->host_binning) {
         // ---- device path: counting sort by (window, source tile) on the GPU (eincm_binning.hip.h) ----
         std::vector<BinBlock> blks;
@@ -707,13 +715,22 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             hipLaunchKernelGGL(k_items, dim3((M + 255) / 256), dim3(256), 0, c->stream, g, seg, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_items);
             if (n_items_total > 0)
                 hipLaunchKernelGGL(k_seg_minmax, dim3(std::min(n_items_total, 4096)), dim3(NT), 0, c->stream, n_items_total, c->d_items, c->d_t);
+            // second segmentation of the same binned events for k_splat
+            hipLaunchKernelGGL(k_bin_tilescan, dim3(1), dim3(1024), 0, c->stream, M, seg_s, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_bin_misc);
+            HIPCHK(c, hipMemcpyAsync(misc, c->d_bin_misc, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            n_items_s_total = misc[1];
+            if (n_items_s_total > c->max_items) return fail(c, EINCM_ERR_ARG, "internal: %d splat segments exceed capacity", n_items_s_total);
+            hipLaunchKernelGGL(k_items, dim3((M + 255) / 256), dim3(256), 0, c->stream, g, seg_s, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_items_s);
+            if (n_items_s_total > 0)
+                hipLaunchKernelGGL(k_seg_minmax, dim3(std::min(n_items_s_total, 4096)), dim3(NT), 0, c->stream, n_items_s_total, c->d_items_s, c->d_t);
             HIPCHK(c, hipGetLastError());
         }
     } else {
     // ---- host path (sensors with more tiles than the LDS histogram holds, or EINCM_HOST_BINNING=1): stable counting sort ----
     std::vector<uint32_t> sxy((size_t)std::max<int64_t>(N, 1));
     std::vector<double> st((size_t)std::max<int64_t>(N, 1));
-    std::vector<Item> items;
+    std::vector<Item> items, items_s;
     std::vector<int64_t> cnt((size_t)g.ntiles + 1);
     int64_t base = 0;
     for (int b = 0; b < n_windows; ++b) {
@@ -735,21 +752,27 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             sxy[d] = (uint32_t)(uint16_t)x[i] | ((uint32_t)(uint16_t)y[i] << 16);
             st[d] = t[i];
         }
-        for (int k = 0; k < g.ntiles; ++k) {
-            for (int64_t s = cnt[k]; s < cnt[k + 1]; s += seg) {
-                Item it;
-                it.win = b; it.tile = k; it.begin = (int32_t)(base + s);
-                it.count = (int32_t)std::min<int64_t>(seg, cnt[k + 1] - s);
-                double lo = st[it.begin], hi = st[it.begin];
-                for (int q = 1; q < it.count; ++q) { lo = std::min(lo, st[it.begin + q]); hi = std::max(hi, st[it.begin + q]); }
-                it.t_lo = lo; it.t_hi = hi;
-                items.push_back(it);
+        for (int pass = 0; pass < 2; ++pass) {
+            const int sg = pass == 0 ? seg : seg_s;
+            std::vector<Item>& dst = pass == 0 ? items : items_s;
+            for (int k = 0; k < g.ntiles; ++k) {
+                for (int64_t s = cnt[k]; s < cnt[k + 1]; s += sg) {
+                    Item it;
+                    it.win = b; it.tile = k; it.begin = (int32_t)(base + s);
+                    it.count = (int32_t)std::min<int64_t>(sg, cnt[k + 1] - s);
+                    double lo = st[it.begin], hi = st[it.begin];
+                    for (int q = 1; q < it.count; ++q) { lo = std::min(lo, st[it.begin + q]); hi = std::max(hi, st[it.begin + q]); }
+                    it.t_lo = lo; it.t_hi = hi;
+                    dst.push_back(it);
+                }
             }
         }
         base += n;
     }
-    if ((int64_t)items.size() > c->max_items) return fail(c, EINCM_ERR_ARG, "internal: %zu work items exceed capacity", items.size());
+    if ((int64_t)items.size() > c->max_items || (int64_t)items_s.size() > c->max_items)
+        return fail(c, EINCM_ERR_ARG, "internal: %zu work items exceed capacity", std::max(items.size(), items_s.size()));
     n_items_total = (int)items.size();
+    n_items_s_total = (int)items_s.size();
     std::vector<float> ef((size_t)n_windows * n_refs * img);
     for (int b = 0; b < n_windows; ++b) {
         WinConst& wc = c->h_wc[b];
@@ -767,13 +790,15 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     }
     if (!items.empty())
         HIPCHK(c, hipMemcpyAsync(c->d_items, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
+    if (!items_s.empty())
+        HIPCHK(c, hipMemcpyAsync(c->d_items_s, items_s.data(), items_s.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_edges, ef.data(), ef.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));     // host vectors go out of scope
     }
     HIPCHK(c, hipMemcpyAsync(c->d_edge_ts, edge_ts, (size_t)n_windows * n_refs * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_mask, 0, (size_t)n_windows * img, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->g = g; c->n_items = n_items_total; c->n_events = N;
+    c->g = g; c->n_items = n_items_total; c->n_items_s = n_items_s_total; c->n_events = N;
     c->win_events.assign(n_events, n_events + n_windows);
     if (c->n_items > 0) {
         hipLaunchKernelGGL(k_mask, dim3(std::min(c->n_items, 2048)), dim3(NT), 0, c->stream, g, c->d_items, c->n_items, c->d_xy, c->d_mask);

@@ -24,8 +24,8 @@ namespace eincm {
 constexpr int TS = 32;            // source tile edge (pixels)
 constexpr int NT = 256;           // threads per workgroup = 4 waves of 64
 constexpr int NWAVE = NT / 64;
-constexpr int WIN_CAP = 4608;     // pixels of LDS for a segment's destination window (u32 chunk + f32 sum = 36 KiB)
-constexpr int WIN_MAXW = 80;
+constexpr int WIN_CAP_DEFAULT = 2304;   // pixels of LDS for a segment's destination window: u32 chunk + f32 sum = 18 KiB -> 8 workgroups/CU
+constexpr int WIN_CAP_MAX = 9216;
 constexpr int NXCD = 8;           // XCDs: blocks b and b+8 share an L2 (round-robin dispatch; speed only, never correctness)
 constexpr double EPSN = 2.220446049250313e-16;   // sys.float_info.epsilon (losses.py:24)
 constexpr float INV_2PI = 0.15915494309189535f;
@@ -48,6 +48,7 @@ constexpr float EXP_M05 = 0.6065306597126334f;   // exp(-1/2)
 struct Geom {
     int H, W, R, B;
     int tilesX, tilesY, ntiles;
+    int wincap, winmaxw;      // LDS destination-window capacity (pixels) and maximum width of the event kernels
 };
 
 struct Item {                     // one segment of event work: <= seg events of one source tile of one window
@@ -151,9 +152,9 @@ __device__ __forceinline__ Window item_window(const Geom& g, const Item& it, con
     int bx0 = x0 + (int)lo[0] - 2, bx1 = x1 + (int)hi[0] + 2;
     int by0 = y0 + (int)lo[1] - 2, by1 = y1 + (int)hi[1] + 2;
     int ww = bx1 - bx0 + 1, wh = by1 - by0 + 1;
-    if (ww * wh > WIN_CAP || ww > WIN_MAXW) {
-        const int nww = min(ww, WIN_MAXW);
-        const int nwh = min(wh, WIN_CAP / nww);
+    if (ww * wh > g.wincap || ww > g.winmaxw) {
+        const int nww = min(ww, g.winmaxw);
+        const int nwh = min(wh, g.wincap / nww);
         bx0 = (bx0 + bx1) / 2 - nww / 2;
         by0 = (by0 + by1) / 2 - nwh / 2;
         ww = nww; wh = nwh;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk,
         float* __restrict__ iwe)               // (B,R,H,W), zeroed
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsu[];
-    float* ldsf = reinterpret_cast<float*>(ldsu + WIN_CAP);
+    float* ldsf = reinterpret_cast<float*>(ldsu + g.wincap);
     int item, r;
     if (!block_to_work(n_items, g.R, item, r)) return;
     const Item it = items[item];
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red11[NWAVE];
-    double* accum = reinterpret_cast<double*>(lds + WIN_CAP);   // TS*TS*2 doubles (ds_add_f64 is ~10x ds_add_f32 on gfx950)
+    double* accum = reinterpret_cast<double*>(lds + g.wincap);   // TS*TS*2 doubles (ds_add_f64 is ~10x ds_add_f32 on gfx950)
     double sum11x = 0.0, sum11y = 0.0;          // direct11: this thread's share of sum_e -dt * dL/dw
     int item, r;
     if (!block_to_work(n_items, g.R, item, r)) return;
