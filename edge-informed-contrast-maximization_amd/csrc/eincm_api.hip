@@ -284,9 +284,14 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool want_grad, co
     }
     {
         StageTimer t(c, EINCM_STAGE_SPLAT);
-        if (c->n_items_s > 0)
-            hipLaunchKernelGGL(k_splat, dim3(splat_grid(c)), dim3(NT), 2 * g.wincap * sizeof(float), c->stream, g, c->n_items_s,
-                               c->chunk, c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe);
+        if (c->n_items_s > 0) {
+            const int theta_mode = (!identity && h == 1 && w == 1) ? THETA_CONST : THETA_TILE;
+            const int lds_multi = (c->seg_s_used > c->chunk) ? 1 : 0;      // segments longer than a chunk need the f32 commit window
+            const size_t lds_bytes = (size_t)(lds_multi ? 2 : 1) * g.wincap * sizeof(float)
+                                   + (theta_mode == THETA_TILE ? TS * TS * sizeof(double2) : 0);
+            hipLaunchKernelGGL(k_splat, dim3(splat_grid(c)), dim3(NT), lds_bytes, c->stream, g, c->n_items_s, c->chunk, theta_mode, lds_multi,
+                               c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return EINCM_OK;
@@ -387,9 +392,10 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
         {
             StageTimer t(c, EINCM_STAGE_GATHER);
             if (c->n_items > 0)
-                hipLaunchKernelGGL(k_gather, dim3(event_grid(c)), dim3(NT), g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double)), c->stream,
+                hipLaunchKernelGGL(k_gather, dim3(event_grid(c)), dim3(NT),
+                               g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), c->stream,
                                g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta,
-                               direct11 ? 1 : 0, c->d_gth, (int)c->coarse_cap);
+                               direct11 ? 1 : 0, c->d_gth, (int)c->coarse_cap, direct11 ? THETA_CONST : THETA_TILE);
         }
         // accumulators: two halves (event gradient | TV gradient), each (maxB, coarse_cap), zeroed by k_theta.
         // 2-DoF theta: k_gather already summed the event gradient into the first half; only the TV image needs projecting.

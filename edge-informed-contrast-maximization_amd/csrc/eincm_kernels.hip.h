@@ -174,7 +174,12 @@ __device__ __forceinline__ void warp_axis(int x, double v, double dt, int& ir, f
     ir = ((unsigned)(ri + (1 << 20)) < (1u << 21)) ? ri : -(1 << 24);   // |w| beyond any sensor: every tap is dropped
 }
 
-struct EvReg { uint32_t xy; double t; double2 v; };   // one event in flight through the 3-stage pipeline of the event kernels
+struct EvReg { uint32_t xy; double t; };   // one event in flight through the software pipeline of the event kernels
+
+// Where an event's velocity Theta[y,x] comes from inside the event kernels.  A per-event global gather costs ~64 L1 cycles per
+// wave-instruction (64 lanes, 64 different cache lines) and was 2/3 of k_splat's time; every workgroup works on ONE source tile, so:
+constexpr int THETA_CONST = 1;   // theta (1,1,2): Theta is one constant per window (read from the tile bounds, min == max)
+constexpr int THETA_TILE = 2;    // otherwise: the tile's 32x32 double2 velocities are staged in LDS once per segment (16 KiB)
 
 // Separable 3-tap weights exp(-0.5*(d - f)^2), d = -1,0,1 (event_utils.py:52-56; the 1/(2*pi) is folded by the caller):
 //   exp(-0.5 (d-f)^2) = exp(-0.5 f^2) * exp(d f) * exp(-0.5 d^2).  Two v_exp_f32 + one v_rcp_f32 (1 ulp each).
@@ -301,7 +306,7 @@ __device__ __forceinline__ bool block_to_work(int n_items, int R, int& item, int
 // A segment is walked in chunks of <= chunk events; each chunk is accumulated in u32 fixed point (exact integer
 // ds_add_u32) and committed into the segment's f32 window; the window is flushed to HBM once per segment.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk,
+__global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, int theta_mode, int lds_multi,
         const Item* __restrict__ items,
         const uint32_t* __restrict__ ev_xy,    // x | y << 16, binned by (window, tile)
         const double* __restrict__ ev_t,
@@ -311,11 +316,24 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk,
         float* __restrict__ iwe)               // (B,R,H,W), zeroed
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsu[];
-    float* ldsf = reinterpret_cast<float*>(ldsu + g.wincap);
+    float* ldsf = reinterpret_cast<float*>(ldsu + g.wincap);                       // present only when lds_multi
+    double2* thtile = reinterpret_cast<double2*>(ldsu + (lds_multi ? 2 : 1) * g.wincap);   // present only for THETA_TILE
     int item, r;
     if (!block_to_work(n_items, g.R, item, r)) return;
     const Item it = items[item];
     const double tau = edge_ts[it.win * g.R + r];
+    const int tx0 = (it.tile % g.tilesX) * TS, ty0 = (it.tile / g.tilesX) * TS;
+    double2 vconst = make_double2(0.0, 0.0);
+    if (theta_mode == THETA_CONST) {
+        const double* mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
+        vconst = make_double2(mm[0], mm[2]);
+    } else {
+        const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
+        for (int p = threadIdx.x; p < TS * TS; p += NT) {
+            const int y = ty0 + p / TS, x = tx0 + p % TS;
+            thtile[p] = (y < g.H && x < g.W) ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : make_double2(0.0, 0.0);
+        }
+    }
     const Window wn = item_window(g, it, tmm + ((size_t)it.win * g.ntiles + it.tile) * 4, tau);
     const int nwin = wn.ww * wn.wh;
     const bool multi = it.count > chunk;
@@ -323,7 +341,6 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk,
     __syncthreads();
 
     float* __restrict__ img = iwe + ((size_t)it.win * g.R + r) * g.H * g.W;
-    const double* __restrict__ Th = Theta + (size_t)it.win * g.H * g.W * 2;
     const uint32_t* __restrict__ exy = ev_xy + it.begin;
     const double* __restrict__ et = ev_t + it.begin;
     const int n = it.count;
@@ -332,20 +349,17 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk,
     int fshift = fix_shift(min(chunk, n));
     float FIX_SCALE = ldexpf(1.0f, fshift), FIX_INV = ldexpf(1.0f, -fshift);
 
-    // Three-stage software pipeline over the segment's events, unrolled x3 with renamed register sets (no rotation
-    // moves, so no forced vmcnt(0)): while event j is splatted, the Theta gather of event j+1 and the (xy, t) loads of
-    // event j+2 are in flight.  Without it the loop is bound by two dependent global-load latencies per event.
-    auto theta_at = [&](uint32_t xy) -> double2 {
-        return *reinterpret_cast<const double2*>(Th + ((size_t)(xy >> 16) * g.W + (xy & 0xffff)) * 2);
-    };
+    // Software pipeline over the segment's events, unrolled x3 with renamed register sets (no rotation moves, so no forced
+    // vmcnt(0)): the (xy, t) loads of event j+2 are in flight while event j is splatted.
     const int tid = threadIdx.x;
     auto load_ev = [&](EvReg& r, int e) { if (e < n) { r.xy = exy[e]; r.t = et[e]; } else { r.xy = 0u; r.t = 0.0; } };
     auto splat_ev = [&](const EvReg& ev) {
         const double dt = ev.t - tau;
         const int x = ev.xy & 0xffff, y = ev.xy >> 16;
+        const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[(y - ty0) * TS + (x - tx0)];
         int irx, iry; float fx, fy;
-        warp_axis(x, ev.v.x, dt, irx, fx);
-        warp_axis(y, ev.v.y, dt, iry, fy);
+        warp_axis(x, v.x, dt, irx, fx);
+        warp_axis(y, v.y, dt, iry, fy);
         float kx[3], ky[3];
         taps3(fx, kx[0], kx[1], kx[2]);
         taps3(fy, ky[0], ky[1], ky[2]);
@@ -374,11 +388,10 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk,
             }
         }
     };
-    // one pipeline step: cur is splatted, mid gets its Theta, nxt gets its (xy, t); j = iteration index of cur
+    // one pipeline step: cur is splatted, nxt gets its (xy, t); j = iteration index of cur
     auto step = [&](EvReg& cur, EvReg& mid, EvReg& nxt, int j) {
         const int e = j * NT + tid;
         load_ev(nxt, e + 2 * NT);
-        mid.v = theta_at(mid.xy);                   // xy = 0 (past the end) is pixel (0,0): a valid address
         if (e < n) splat_ev(cur);
         if (multi && ((j + 1) % ipc == 0 || j + 1 == iters)) {     // chunk boundary (uniform): commit u32 -> f32 window
             __syncthreads();
@@ -394,8 +407,7 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk,
     EvReg A, B, C;
     load_ev(A, tid);
     load_ev(B, tid + NT);
-    A.v = theta_at(A.xy);
-    C.xy = 0u; C.t = 0.0; C.v = make_double2(0.0, 0.0);
+    C.xy = 0u; C.t = 0.0;
     for (int j = 0; j < iters; j += 3) {
         step(A, B, C, j);
         if (j + 1 < iters) step(B, C, A, j + 1);
@@ -776,11 +788,14 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         const double* __restrict__ Theta, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
         const float* __restrict__ G,           // (B,R,H,W)
         float* __restrict__ gTheta,            // (B,H,W,2), zeroed
-        int direct11, double* __restrict__ gth_main, int gth_cap)   // 2-DoF theta: sum straight into dL/dtheta (B,gth_cap)
+        int direct11, double* __restrict__ gth_main, int gth_cap,   // 2-DoF theta: sum straight into dL/dtheta (B,gth_cap)
+        int theta_mode)
 {
+    // LDS: [G window: wincap floats][accum: TS*TS*2 doubles unless direct11][Theta tile: TS*TS double2 if THETA_TILE]
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red11[NWAVE];
-    double* accum = reinterpret_cast<double*>(lds + g.wincap);   // TS*TS*2 doubles (ds_add_f64 is ~10x ds_add_f32 on gfx950)
+    double* accum = reinterpret_cast<double*>(lds + g.wincap);   // ds_add_f64 is ~10x ds_add_f32 on gfx950
+    double2* thtile = reinterpret_cast<double2*>(lds + g.wincap + (direct11 ? 0 : TS * TS * 4));
     double sum11x = 0.0, sum11y = 0.0;          // direct11: this thread's share of sum_e -dt * dL/dw
     int item, r;
     if (!block_to_work(n_items, g.R, item, r)) return;
@@ -798,26 +813,34 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     }
     if (!direct11)
         for (int i = threadIdx.x; i < TS * TS * 2; i += NT) accum[i] = 0.0;
-    __syncthreads();
-
     const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
-    const double* __restrict__ Th = Theta + (size_t)it.win * g.H * g.W * 2;
+    double2 vconst = make_double2(0.0, 0.0);
+    if (theta_mode == THETA_CONST) {
+        const double* mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
+        vconst = make_double2(mm[0], mm[2]);
+    } else {
+        const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
+        for (int p = threadIdx.x; p < TS * TS; p += NT) {
+            const int y = y0 + p / TS, x = x0 + p % TS;
+            thtile[p] = (y < g.H && x < g.W) ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : make_double2(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+
     const uint32_t* __restrict__ exy = ev_xy + it.begin;
     const double* __restrict__ et = ev_t + it.begin;
     const int n = it.count;
     const int iters = (n + NT - 1) / NT;
-    auto theta_at = [&](uint32_t xy) -> double2 {
-        return *reinterpret_cast<const double2*>(Th + ((size_t)(xy >> 16) * g.W + (xy & 0xffff)) * 2);
-    };
     const int tid = threadIdx.x;
     auto load_ev = [&](EvReg& r, int e) { if (e < n) { r.xy = exy[e]; r.t = et[e]; } else { r.xy = 0u; r.t = 0.0; } };
     auto gather_ev = [&](const EvReg& ev) {
         const double dt = ev.t - tau;
         const int x = ev.xy & 0xffff, y = ev.xy >> 16;
+        const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[(y - y0) * TS + (x - x0)];
         int irx, iry; float fx, fy;
-        warp_axis(x, ev.v.x, dt, irx, fx);
-        warp_axis(y, ev.v.y, dt, iry, fy);
+        warp_axis(x, v.x, dt, irx, fx);
+        warp_axis(y, v.y, dt, iry, fy);
         float kx[3], ky[3];
         taps3(fx, kx[0], kx[1], kx[2]);
         taps3(fy, ky[0], ky[1], ky[2]);
@@ -871,18 +894,16 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
             atomicAdd(a + 1, -dt * (double)gwy);
         }
     };
-    // three-stage pipeline with renamed register sets, as in k_splat
+    // software pipeline with renamed register sets, as in k_splat
     auto step = [&](EvReg& cur, EvReg& mid, EvReg& nxt, int j) {
         const int e = j * NT + tid;
         load_ev(nxt, e + 2 * NT);
-        mid.v = theta_at(mid.xy);
         if (e < n) gather_ev(cur);
     };
     EvReg A, B, C;
     load_ev(A, tid);
     load_ev(B, tid + NT);
-    A.v = theta_at(A.xy);
-    C.xy = 0u; C.t = 0.0; C.v = make_double2(0.0, 0.0);
+    C.xy = 0u; C.t = 0.0;
     for (int j = 0; j < iters; j += 3) {
         step(A, B, C, j);
         if (j + 1 < iters) step(B, C, A, j + 1);
