@@ -38,7 +38,7 @@ struct eincm_ctx {
     int H = 0, W = 0, maxR = 0, maxB = 0;
     int64_t maxN = 0;
     uint32_t cflags = 0;
-    int chunk = 2048;              // events per inner chunk of k_splat (u32 accumulation bound)
+    int chunk = 4096;              // events per inner chunk of k_splat (u32 accumulation bound): = default splat segment, so no commit pass
     int seg = 0;                   // events per segment (0 = choose per batch); EINCM_SEG / EINCM_CHUNK override
     int seg_used = 0;
     hipStream_t stream = nullptr;

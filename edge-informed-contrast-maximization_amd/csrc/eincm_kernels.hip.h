@@ -337,7 +337,12 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     const Window wn = item_window(g, it, tmm + ((size_t)it.win * g.ntiles + it.tile) * 4, tau);
     const int nwin = wn.ww * wn.wh;
     const bool multi = it.count > chunk;
-    for (int i = threadIdx.x; i < nwin; i += NT) { ldsu[i] = 0u; if (multi) ldsf[i] = 0.0f; }
+    {   // clear the window(s), 16 B per lane
+        uint4* z = reinterpret_cast<uint4*>(ldsu);
+        const int nq = (nwin + 3) >> 2;
+        for (int i = threadIdx.x; i < nq; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (multi) { uint4* zf = reinterpret_cast<uint4*>(ldsf); for (int i = threadIdx.x; i < nq; i += NT) zf[i] = make_uint4(0u, 0u, 0u, 0u); }
+    }
     __syncthreads();
 
     float* __restrict__ img = iwe + ((size_t)it.win * g.R + r) * g.H * g.W;
