@@ -171,7 +171,28 @@ __device__ __forceinline__ void warp_axis(int x, double v, double dt, int& ir, f
     const double r = rint(w);
     f = (float)(w - r);                              // garbage when the event is off-sensor, but then every tap is dropped
     const int ri = (int)r;                           // v_cvt_i32_f64 saturates (NaN -> 0; a NaN theta is caught in k_final)
-    ir = ((unsigned)(ri + (1 << 20)) < (1u << 21)) ? ri : -(1 << 24);   // |w| beyond any sensor: every tap is dropped
+    ir = min(max(ri, -(1 << 20)), 1 << 20);          // one v_med3_i32; |w| beyond any sensor (W, H <= 32767): every tap is dropped
+}
+
+typedef float f2v __attribute__((ext_vector_type(2)));   // (x-axis value, y-axis value): lowers to v_pk_mul_f32 / v_pk_fma_f32
+
+// Separable 3-tap weights of BOTH axes at once, packed fp32: k(d) = exp(-0.5 (d - f)^2) = exp(-0.5 f^2) exp(d f) exp(-0.5 d^2),
+// d = -1, 0, 1 (event_utils.py:52-56).  The y weights carry `scale_y` (1/(2 pi), times the fixed-point scale in k_splat).
+// 4 v_exp_f32 + 2 v_rcp_f32 (1 ulp each) + 7 packed multiplies.
+__device__ __forceinline__ void taps3x2(float fx, float fy, float scale_y, f2v& km, f2v& k0, f2v& kp) {
+    constexpr float L2E = 1.4426950408889634f;
+    const f2v f = {fx, fy};
+    const f2v a = (f * f) * (-0.5f * L2E);
+    const f2v b = f * L2E;
+    f2v e0 = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const f2v ep = {__builtin_amdgcn_exp2f(b.x), __builtin_amdgcn_exp2f(b.y)};
+    const f2v em = {__builtin_amdgcn_rcpf(ep.x), __builtin_amdgcn_rcpf(ep.y)};
+    const f2v sc = {1.0f, scale_y};
+    e0 = e0 * sc;
+    const f2v c = e0 * EXP_M05;
+    km = c * em;                // d = -1
+    k0 = e0;
+    kp = c * ep;                // d = +1
 }
 
 struct EvReg { uint32_t xy; double t; };   // one event in flight through the software pipeline of the event kernels
@@ -180,19 +201,6 @@ struct EvReg { uint32_t xy; double t; };   // one event in flight through the so
 // wave-instruction (64 lanes, 64 different cache lines) and was 2/3 of k_splat's time; every workgroup works on ONE source tile, so:
 constexpr int THETA_CONST = 1;   // theta (1,1,2): Theta is one constant per window (read from the tile bounds, min == max)
 constexpr int THETA_TILE = 2;    // otherwise: the tile's 32x32 double2 velocities are staged in LDS once per segment (16 KiB)
-
-// Separable 3-tap weights exp(-0.5*(d - f)^2), d = -1,0,1 (event_utils.py:52-56; the 1/(2*pi) is folded by the caller):
-//   exp(-0.5 (d-f)^2) = exp(-0.5 f^2) * exp(d f) * exp(-0.5 d^2).  Two v_exp_f32 + one v_rcp_f32 (1 ulp each).
-__device__ __forceinline__ void taps3(float f, float& wm, float& w0, float& wp) {
-    constexpr float L2E = 1.4426950408889634f;
-    const float e0 = __builtin_amdgcn_exp2f(f * f * (-0.5f * L2E));
-    const float ep = __builtin_amdgcn_exp2f(f * L2E);
-    const float em = __builtin_amdgcn_rcpf(ep);
-    const float c = e0 * EXP_M05;
-    wm = c * em;                // d = -1: exp(-0.5 f^2 - f - 0.5)
-    w0 = e0;
-    wp = c * ep;                // d = +1
-}
 
 // round-to-nearest fixed-point conversion of a positive value: fma + truncating convert (2 instructions)
 __device__ __forceinline__ uint32_t fix_u32(float a, float b) { return (uint32_t)fmaf(a, b, 0.5f); }
@@ -358,26 +366,34 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     // vmcnt(0)): the (xy, t) loads of event j+2 are in flight while event j is splatted.
     const int tid = threadIdx.x;
     auto load_ev = [&](EvReg& r, int e) { if (e < n) { r.xy = exy[e]; r.t = et[e]; } else { r.xy = 0u; r.t = 0.0; } };
+    const float scale_y = INV_2PI * FIX_SCALE;      // single-chunk segments: constant over the loop (re-derived after a commit)
+    float scy = scale_y;
     auto splat_ev = [&](const EvReg& ev) {
         const double dt = ev.t - tau;
         const int x = ev.xy & 0xffff, y = ev.xy >> 16;
-        const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[(y - ty0) * TS + (x - tx0)];
+        // tiles start at multiples of TS = 32, so the in-tile index is (y & 31) * 32 + (x & 31)
+        const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)];
         int irx, iry; float fx, fy;
         warp_axis(x, v.x, dt, irx, fx);
         warp_axis(y, v.y, dt, iry, fy);
-        float kx[3], ky[3];
-        taps3(fx, kx[0], kx[1], kx[2]);
-        taps3(fy, ky[0], ky[1], ky[2]);
-        ky[0] *= INV_2PI * FIX_SCALE; ky[1] *= INV_2PI * FIX_SCALE; ky[2] *= INV_2PI * FIX_SCALE;
+        f2v km, k0, kp;                              // .x = x-axis weight, .y = y-axis weight (scaled)
+        taps3x2(fx, fy, scy, km, k0, kp);
         const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;        // window coords of the top-left tap
         if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
-            uint32_t* p = ldsu + ly * wn.ww + lx;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) atomicAdd(p + dy * wn.ww + dx, fix_u32(ky[dy], kx[dx]));
-            }
+            uint32_t* p = ldsu + __mul24(ly, wn.ww) + lx;
+            // 3x3 products ky[dy]*kx[dx] + 0.5 as 4 packed FMAs + 1 scalar, then truncating converts
+            const f2v half = {0.5f, 0.5f};
+            const f2v kx01 = {km.x, k0.x};
+            const f2v r0 = kx01 * km.y + half, r1 = kx01 * k0.y + half, r2 = kx01 * kp.y + half;
+            const f2v ky01 = {km.y, k0.y};
+            const f2v c2 = ky01 * kp.x + half;       // column dx = 2 of rows 0, 1
+            const float c22 = fmaf(kp.y, kp.x, 0.5f);
+            uint32_t* p1 = p + wn.ww; uint32_t* p2 = p1 + wn.ww;
+            atomicAdd(p, (uint32_t)r0.x); atomicAdd(p + 1, (uint32_t)r0.y); atomicAdd(p + 2, (uint32_t)c2.x);
+            atomicAdd(p1, (uint32_t)r1.x); atomicAdd(p1 + 1, (uint32_t)r1.y); atomicAdd(p1 + 2, (uint32_t)c2.y);
+            atomicAdd(p2, (uint32_t)r2.x); atomicAdd(p2 + 1, (uint32_t)r2.y); atomicAdd(p2 + 2, (uint32_t)c22);
         } else {
+            const float kx[3] = {km.x, k0.x, kp.x}, ky[3] = {km.y, k0.y, kp.y};
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
@@ -407,6 +423,7 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
             __syncthreads();
             fshift = fix_shift(min(chunk, n - (j + 1) * NT));
             FIX_SCALE = ldexpf(1.0f, fshift); FIX_INV = ldexpf(1.0f, -fshift);
+            scy = INV_2PI * FIX_SCALE;
         }
     };
     EvReg A, B, C;
@@ -842,18 +859,17 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     auto gather_ev = [&](const EvReg& ev) {
         const double dt = ev.t - tau;
         const int x = ev.xy & 0xffff, y = ev.xy >> 16;
-        const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[(y - y0) * TS + (x - x0)];
+        const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)];
         int irx, iry; float fx, fy;
         warp_axis(x, v.x, dt, irx, fx);
         warp_axis(y, v.y, dt, iry, fy);
-        float kx[3], ky[3];
-        taps3(fx, kx[0], kx[1], kx[2]);
-        taps3(fy, ky[0], ky[1], ky[2]);
-        ky[0] *= INV_2PI; ky[1] *= INV_2PI; ky[2] *= INV_2PI;
+        f2v km, k0, kp;
+        taps3x2(fx, fy, INV_2PI, km, k0, kp);
+        const float kx[3] = {km.x, k0.x, kp.x}, ky[3] = {km.y, k0.y, kp.y};
         float gv[3][3];
         const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;
         if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
-            const float* p = lds + ly * wn.ww + lx;
+            const float* p = lds + __mul24(ly, wn.ww) + lx;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
@@ -894,7 +910,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         if (direct11) {          // theta (1,1,2): Theta is constant, dL/dtheta = sum over all events; no per-pixel image needed
             sum11x -= dt * (double)gwx; sum11y -= dt * (double)gwy;
         } else {
-            double* a = accum + ((y - y0) * TS + (x - x0)) * 2;
+            double* a = accum + ((((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)) << 1);
             atomicAdd(a, -dt * (double)gwx);
             atomicAdd(a + 1, -dt * (double)gwy);
         }
