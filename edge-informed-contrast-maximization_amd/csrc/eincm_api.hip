@@ -79,6 +79,7 @@ struct eincm_ctx {
     double* d_tmm = nullptr;       // (B,ntiles,4)
     StatPart* d_parts = nullptr;   // (B,R,ntiles)
     double* d_divparts = nullptr;  // (B,R,ntiles)
+    double* d_g2parts = nullptr;   // (B,R,ntiles) contrast energy partials written by k_imgrad
     float* d_gdiv = nullptr;       // (B,R,H,W) divergence adjoint image, allocated on first delta != 0 gradient
     double* d_dgparts = nullptr;   // (B,R,ntiles,2)
     double* d_tvparts = nullptr;   // (B,ntiles,3)
@@ -197,7 +198,7 @@ void free_all(eincm_ctx* c) {
     F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_items_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
     F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
-    F(c->d_divparts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
+    F(c->d_divparts); F(c->d_g2parts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
     F(c->d_rowtap); F(c->d_coltap);
     auto FH = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
     FH(c->h_theta); FH(c->h_outs); c->h_grad = nullptr; FH(c->h_wc);
@@ -358,7 +359,7 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
 int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
     if (!c->pend.active) return fail(c, EINCM_ERR_STATE, "no evaluation in flight");
     c->pend.active = false;
-    const Geom& g = c->g;
+    Geom g = c->g;
     const EvalParams ep = c->pend.ep;
     const int h = c->pend.h, w = c->pend.w;
     const bool identity = c->pend.identity, want_grad = c->pend.want_grad, full_aux = c->pend.full_aux, div_grad = c->pend.div_grad;
@@ -366,9 +367,19 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
     const bool timing = (c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)) != 0;
     if (want_grad && !grad) return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
     int rc = EINCM_OK;
+    const bool g2_from_imgrad = want_grad && ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG;
     {
         StageTimer t(c, EINCM_STAGE_STATS);
-        hipLaunchKernelGGL(k_stats, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_edges, c->d_parts);
+        // Gradient evaluations with the grad-mag contrast take the contrast energy from k_imgrad (which computes the Scharr
+        // images anyway), so the statistics are a pure streaming reduction with NSPART fat partials per image.
+        if (g2_from_imgrad && g.ntiles >= NSPART) {
+            g.nparts = NSPART;
+            hipLaunchKernelGGL(k_stats_stream, dim3(NSPART, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_edges, c->d_parts);
+        } else {
+            g.nparts = g.ntiles;
+            hipLaunchKernelGGL(k_stats, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_edges, c->d_parts,
+                               g2_from_imgrad ? 0 : 1);
+        }
     }
 
     if (ep.want_div) {
@@ -387,7 +398,7 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
                 hipLaunchKernelGGL(k_divgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_parts,
                                    c->d_gdiv, c->d_dgparts);
             hipLaunchKernelGGL(k_imgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, ep, c->d_iwe, c->d_edges,
-                               c->d_parts, c->d_wc, c->d_gdiv, c->d_dgparts, c->d_G);
+                               c->d_parts, c->d_wc, c->d_gdiv, c->d_dgparts, c->d_g2parts, c->d_G);
         }
         {
             StageTimer t(c, EINCM_STAGE_GATHER);
@@ -410,7 +421,7 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
     {
         StageTimer t(c, EINCM_STAGE_FINAL);
         hipLaunchKernelGGL(k_final, dim3(g.B), dim3(NT), 0, c->stream, g, ep, c->d_parts, c->d_divparts, c->d_tvparts,
-                           c->d_tmm, c->d_wc, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap,
+                           c->d_tmm, c->d_wc, g2_from_imgrad ? c->d_g2parts : nullptr, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap,
                            c->d_outs, c->d_grad, want_grad ? 1 : 0);
         if (want_grad && identity) {
             hipLaunchKernelGGL(k_final_dense, dim3(256, g.B), dim3(NT), 0, c->stream, g, ep.use_tv_grad, c->d_gTheta,
@@ -588,6 +599,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_tmm, B * ntiles * 4));
     TRY(dalloc(&c->d_parts, B * R * ntiles));
     TRY(dalloc(&c->d_divparts, B * R * ntiles));
+    TRY(dalloc(&c->d_g2parts, B * R * ntiles));
     TRY(dalloc(&c->d_tvparts, B * ntiles * 3));
     TRY(dalloc(&c->d_wc, B));
     {   // one device block and one pinned block: [OutScal x B | grad (B,H,W,2)] -> a single D2H copy per evaluation

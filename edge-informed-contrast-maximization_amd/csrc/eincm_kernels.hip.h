@@ -49,6 +49,7 @@ struct Geom {
     int H, W, R, B;
     int tilesX, tilesY, ntiles;
     int wincap, winmaxw;      // LDS destination-window capacity (pixels) and maximum width of the event kernels
+    int nparts;               // StatParts per image written by the statistics kernel of this evaluation (ntiles or NSPART)
 };
 
 struct Item {                     // one segment of event work: <= seg events of one source tile of one window
@@ -472,7 +473,7 @@ template <typename A> __device__ __forceinline__ void scharr_at(const A& a, int 
 // k_stats: grid (ntiles, R, B).  img_of_r: stride between reference images (0 when one image serves all refs).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_stats(Geom g, const float* __restrict__ iwe, const float* __restrict__ edges,
-                                               StatPart* __restrict__ parts)
+                                               StatPart* __restrict__ parts, int with_contrast)
 {
     constexpr int P = TS + 2, PP = P + 1;
     __shared__ float t[P][PP];
@@ -482,26 +483,32 @@ __global__ __launch_bounds__(NT) void k_stats(Geom g, const float* __restrict__ 
     const int x0 = tx * TS, y0 = ty * TS;
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
     const float* __restrict__ E = edges + ((size_t)b * g.R + r) * g.H * g.W;
-    for (int p = threadIdx.x; p < P * P; p += NT) {
-        const int ly = p / P, lx = p % P;
-        const int y = y0 + ly - 1, x = x0 + lx - 1;
-        t[ly][lx] = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? I[(size_t)y * g.W + x] : 0.0f;
+    // with_contrast = 0 (gradient evaluations): k_imgrad computes the Scharr images anyway and accumulates the contrast
+    // energy itself, so this kernel is a pure streaming reduction (no LDS tile, no halo, no stencil).
+    if (with_contrast) {
+        for (int p = threadIdx.x; p < P * P; p += NT) {
+            const int ly = p / P, lx = p % P;
+            const int y = y0 + ly - 1, x = x0 + lx - 1;
+            t[ly][lx] = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? I[(size_t)y * g.W + x] : 0.0f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     auto acc = [&](int y, int x) -> double { return (double)t[y][x]; };
     double mn = INFINITY, mx = -INFINITY, cmn = 0.0, cmx = 0.0, sI = 0.0, sII = 0.0, sEI = 0.0, sG2 = 0.0;
     for (int p = threadIdx.x; p < TS * TS; p += NT) {
         const int ly = p / TS, lx = p % TS;
         const int y = y0 + ly, x = x0 + lx;
         if (y >= g.H || x >= g.W) continue;
-        const double v = acc(ly + 1, lx + 1);
+        const double v = with_contrast ? acc(ly + 1, lx + 1) : (double)I[(size_t)y * g.W + x];
         const double e = (double)E[(size_t)y * g.W + x];
         if (v < mn) { mn = v; cmn = 1.0; } else if (v == mn) cmn += 1.0;
         if (v > mx) { mx = v; cmx = 1.0; } else if (v == mx) cmx += 1.0;
         sI += v; sII += v * v; sEI += e * v;
-        double gx, gy;
-        scharr_at(acc, ly + 1, lx + 1, gx, gy);
-        sG2 += gx * gx + gy * gy;
+        if (with_contrast) {
+            double gx, gy;
+            scharr_at(acc, ly + 1, lx + 1, gx, gy);
+            sG2 += gx * gx + gy * gy;
+        }
     }
     // (min,count) / (max,count) pairs combine associatively
     const double wmn = wave_min(mn), wmx = wave_max(mx);
@@ -525,6 +532,45 @@ __global__ __launch_bounds__(NT) void k_stats(Geom g, const float* __restrict__ 
             o.sI += red[i][4]; o.sII += red[i][5]; o.sEI += red[i][6]; o.sG2 += red[i][7];
         }
         parts[((size_t)b * g.R + r) * g.ntiles + tile] = o;
+    }
+}
+
+// k_stats_stream: the same partials as k_stats without the contrast energy, as a pure streaming reduction.  The partials have
+// no per-tile meaning (they are only ever reduced over the whole image), so NSPART fat blocks per image read the image with
+// coalesced grid-stride loads and pay the fp64 cross-lane reduction once each.  grid (NSPART, R, B).
+constexpr int NSPART = 32;
+__global__ __launch_bounds__(NT) void k_stats_stream(Geom g, const float* __restrict__ iwe, const float* __restrict__ edges,
+                                                      StatPart* __restrict__ parts)
+{
+    __shared__ double red[NWAVE][8];
+    const int part = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
+    const size_t n = (size_t)g.H * g.W;
+    const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * n;
+    const float* __restrict__ E = edges + ((size_t)b * g.R + r) * n;
+    double mn = INFINITY, mx = -INFINITY, cmn = 0.0, cmx = 0.0, sI = 0.0, sII = 0.0, sEI = 0.0;
+    for (size_t i = (size_t)part * NT + threadIdx.x; i < n; i += (size_t)NSPART * NT) {
+        const double v = (double)I[i], e = (double)E[i];
+        if (v < mn) { mn = v; cmn = 1.0; } else if (v == mn) cmn += 1.0;
+        if (v > mx) { mx = v; cmx = 1.0; } else if (v == mx) cmx += 1.0;
+        sI += v; sII += v * v; sEI += e * v;
+    }
+    const double wmn = wave_min(mn), wmx = wave_max(mx);
+    const double bmn = __shfl(wmn, 0, 64), bmx = __shfl(wmx, 0, 64);
+    cmn = wave_sum(mn == bmn ? cmn : 0.0);
+    cmx = wave_sum(mx == bmx ? cmx : 0.0);
+    sI = wave_sum(sI); sII = wave_sum(sII); sEI = wave_sum(sEI);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[wv][0] = bmn; red[wv][1] = bmx; red[wv][2] = cmn; red[wv][3] = cmx; red[wv][4] = sI; red[wv][5] = sII; red[wv][6] = sEI; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        StatPart o;
+        o.mn = red[0][0]; o.mx = red[0][1]; o.cmn = red[0][2]; o.cmx = red[0][3]; o.sI = red[0][4]; o.sII = red[0][5]; o.sEI = red[0][6]; o.sG2 = 0.0;
+        for (int i = 1; i < NWAVE; ++i) {
+            if (red[i][0] < o.mn) { o.mn = red[i][0]; o.cmn = red[i][2]; } else if (red[i][0] == o.mn) o.cmn += red[i][2];
+            if (red[i][1] > o.mx) { o.mx = red[i][1]; o.cmx = red[i][3]; } else if (red[i][1] == o.mx) o.cmx += red[i][3];
+            o.sI += red[i][4]; o.sII += red[i][5]; o.sEI += red[i][6];
+        }
+        parts[((size_t)b * g.R + r) * g.ntiles + part] = o;      // slots [0, NSPART) of the image's ntiles-sized row (ntiles >= NSPART checked on the host)
     }
 }
 
@@ -565,11 +611,13 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
         const float* __restrict__ iwe, const float* __restrict__ edges,
         const StatPart* __restrict__ parts, const WinConst* __restrict__ wc,
         const float* __restrict__ gdiv, const double* __restrict__ dgparts,    // delta != 0 only (else unused)
+        double* __restrict__ g2parts,          // (B,R,ntiles): this tile's sum of gx^2+gy^2 (contrast energy), a by-product
         float* __restrict__ G)
 {
+    __shared__ double g2scratch[NWAVE];
     constexpr int P2 = TS + 4, P1 = TS + 2;
     __shared__ float t[P2][P2 + 1];
-    __shared__ double sgx[P1][P1 + 1], sgy[P1][P1 + 1];
+    __shared__ float sgx[P1][P1 + 1], sgy[P1][P1 + 1];   // fp32 stencils: inputs (IWE) and output (G) are fp32 images
     __shared__ double sc[9];
     const bool use_div = (ep.delta != 0.0);
     const int tile = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
@@ -582,7 +630,7 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
     const WinConst& c = wc[b];
 
     if (threadIdx.x < 64) {
-        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.ntiles);
+        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
         double dAn = 0.0, dA = 0.0;
         if (use_div) {
             const double* dp = dgparts + ((size_t)b * g.R + r) * g.ntiles * 2;
@@ -616,17 +664,26 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
         t[ly][lx] = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? I[(size_t)y * g.W + x] : 0.0f;
     }
     __syncthreads();
+    double g2 = 0.0;
     if (ep.contrast_kind == 0) {
-        auto acc = [&](int y, int x) -> double { return (double)t[y][x]; };
+        float g2f = 0.0f;
         for (int p = threadIdx.x; p < P1 * P1; p += NT) {
             const int ly = p / P1, lx = p % P1;
             const int y = y0 + ly - 1, x = x0 + lx - 1;
-            double gx = 0.0, gy = 0.0;
-            if (y >= 0 && y < g.H && x >= 0 && x < g.W) scharr_at(acc, ly + 1, lx + 1, gx, gy);   // zero outside the image
+            float gx = 0.0f, gy = 0.0f;
+            if (y >= 0 && y < g.H && x >= 0 && x < g.W) {   // zero outside the image
+                const int cy = ly + 1, cx = lx + 1;
+                gx = 3.0f * (t[cy + 1][cx + 1] - t[cy + 1][cx - 1]) + 10.0f * (t[cy][cx + 1] - t[cy][cx - 1]) + 3.0f * (t[cy - 1][cx + 1] - t[cy - 1][cx - 1]);
+                gy = 3.0f * (t[cy + 1][cx + 1] - t[cy - 1][cx + 1]) + 10.0f * (t[cy + 1][cx] - t[cy - 1][cx]) + 3.0f * (t[cy + 1][cx - 1] - t[cy - 1][cx - 1]);
+            }
             sgx[ly][lx] = gx; sgy[ly][lx] = gy;
+            if (ly >= 1 && ly <= TS && lx >= 1 && lx <= TS) g2f += gx * gx + gy * gy;   // own pixels only (zero outside the image)
         }
+        g2 = (double)g2f;
         __syncthreads();
     }
+    g2 = block_sum(g2, g2scratch);
+    if (threadIdx.x == 0) g2parts[((size_t)b * g.R + r) * g.ntiles + tile] = g2;
     const double m = sc[0], M = sc[1], D = sc[2];
     for (int p = threadIdx.x; p < TS * TS; p += NT) {
         const int ly = p / TS, lx = p % TS;
@@ -637,11 +694,11 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
         if (ep.contrast_kind == 0) {
             // adj_Sx(gx) = -conv(gx, Sx), adj_Sy(gy) = -conv(gy, Sy)
             const int cy = ly + 1, cx = lx + 1;
-            const double ax = 3.0 * (sgx[cy + 1][cx + 1] - sgx[cy + 1][cx - 1]) + 10.0 * (sgx[cy][cx + 1] - sgx[cy][cx - 1])
-                            + 3.0 * (sgx[cy - 1][cx + 1] - sgx[cy - 1][cx - 1]);
-            const double ay = 3.0 * (sgy[cy + 1][cx + 1] - sgy[cy - 1][cx + 1]) + 10.0 * (sgy[cy + 1][cx] - sgy[cy - 1][cx])
-                            + 3.0 * (sgy[cy + 1][cx - 1] - sgy[cy - 1][cx - 1]);
-            dc = -(ax + ay);
+            const float ax = 3.0f * (sgx[cy + 1][cx + 1] - sgx[cy + 1][cx - 1]) + 10.0f * (sgx[cy][cx + 1] - sgx[cy][cx - 1])
+                           + 3.0f * (sgx[cy - 1][cx + 1] - sgx[cy - 1][cx - 1]);
+            const float ay = 3.0f * (sgy[cy + 1][cx + 1] - sgy[cy - 1][cx + 1]) + 10.0f * (sgy[cy + 1][cx] - sgy[cy - 1][cx])
+                           + 3.0f * (sgy[cy + 1][cx - 1] - sgy[cy - 1][cx - 1]);
+            dc = -(double)(ax + ay);
         } else {
             dc = v - sc[7];
         }
@@ -673,7 +730,7 @@ __global__ __launch_bounds__(NT) void k_div(Geom g, const float* __restrict__ iw
     const int x0 = tx * TS, y0 = ty * TS;
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
     if (threadIdx.x < 64) {
-        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.ntiles);
+        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
         if (threadIdx.x == 0) { sc[0] = s.m; sc[1] = s.D; }
     }
     __syncthreads();
@@ -729,7 +786,7 @@ __global__ __launch_bounds__(NT) void k_divgrad(Geom g, const float* __restrict_
     const int x0 = tx * TS, y0 = ty * TS;
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
     if (threadIdx.x < 64) {
-        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.ntiles);
+        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
         if (threadIdx.x == 0) { sc[0] = s.m; sc[1] = s.D; }
     }
     __syncthreads();
@@ -1201,6 +1258,7 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
 __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
         const StatPart* __restrict__ parts, const double* __restrict__ divparts, const double* __restrict__ tvparts,
         const double* __restrict__ tmm, const WinConst* __restrict__ wc,
+        const double* __restrict__ g2parts,    // contrast energy partials from k_imgrad, or nullptr (then parts[].sG2 holds it)
         const double* __restrict__ gth_main, const double* __restrict__ gth_tv, int gth_cap,
         OutScal* __restrict__ outs, double* __restrict__ grad_out, int want_grad)
 {
@@ -1218,13 +1276,19 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
             for (int i = threadIdx.x; i < g.ntiles; i += NT) v += divparts[((size_t)b * g.R + r) * g.ntiles + i];
             dsum = block_sum(v, scratch);
         }
+        double g2sum = 0.0;
+        if (g2parts) {
+            double v = 0.0;
+            for (int i = threadIdx.x; i < g.ntiles; i += NT) v += g2parts[((size_t)b * g.R + r) * g.ntiles + i];
+            g2sum = block_sum(v, scratch);
+        }
         if (threadIdx.x < 64) {
-            const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.ntiles);
+            const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
             if (threadIdx.x == 0) {
                 const double mse = mse_from_moments(s, c.sE[r], c.sEE[r], HW);
                 const double mean = s.sI / HW;
                 const double var = s.sII / HW - mean * mean;
-                const double cgm = s.sG2 / HW;
+                const double cgm = (g2parts ? g2sum : s.sG2) / HW;
                 const double con = (ep.contrast_kind == 1) ? var : cgm;
                 const double c0 = (ep.contrast_kind == 1) ? c.c0_var : c.c0_gradmag;
                 const double dv = ep.want_div ? dsum / HW : NAN;
