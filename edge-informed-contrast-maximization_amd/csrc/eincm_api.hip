@@ -58,6 +58,7 @@ struct eincm_ctx {
     Item* d_items_s = nullptr;     // (max_items) shorter segments walked by k_splat
     int n_items_s = 0; int seg_s = 0; int seg_s_used = 0;
     int wincap = WIN_CAP_DEFAULT;
+    bool wincap_fixed = false;     // EINCM_WINCAP pins the capacity; otherwise it is chosen per evaluation from max|theta|
     // device-side staging (eincm_binning.hip.h)
     int16_t* d_raw_x = nullptr; int16_t* d_raw_y = nullptr; double* d_raw_t = nullptr;   // (maxN) events as handed over
     BinBlock* d_binblocks = nullptr; int32_t* d_win_blk = nullptr; uint32_t* d_blockhist = nullptr;
@@ -348,6 +349,24 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     ep.use_tv_grad = (ep.want_tv && p->gamma != 0.0 && want_grad && !(p->flags & EINCM_PF_NO_TV_GRAD)) ? 1 : 0;
     ep.h = h; ep.w = w; ep.identity = identity ? 1 : 0;
 
+    // LDS window capacity for this evaluation: the host knows theta, hence the largest displacement a segment can see.
+    // Small windows give 8 workgroups per CU; windows too small for the flow push taps onto the slow direct-to-HBM path.
+    if (!c->wincap_fixed) {
+        double vmax = 0.0;
+        const size_t nall = (size_t)g.B * nth;
+        const size_t stride = nall > 65536 ? nall / 65536 : 1;          // dense theta: sample (any capacity is correct)
+        for (size_t i = 0; i < nall; i += stride) { const double a = std::fabs(theta_host[i]); if (a > vmax && std::isfinite(a)) vmax = a; }
+        // time span of a typical splat segment: seg_s events out of the average tile population
+        const double per_tile = (double)std::max<int64_t>(c->n_events, 1) / ((double)g.B * g.ntiles);
+        const double tspan = std::min(1.0, (double)c->seg_s_used / std::max(per_tile, 1.0));
+        const double side = TS + 4 + vmax * tspan;
+        const double need = side * side;
+        static const int caps[] = {2304, 3072, 4608, 6912};      // 6912 keeps k_gather's LDS (window + accumulators + Theta tile) under 64 KiB
+        int cap = caps[3];
+        for (int k = 0; k < 4; ++k) if (need <= caps[k]) { cap = caps[k]; break; }
+        c->g.wincap = cap;
+        c->g.winmaxw = std::max(40, (int)std::lround(std::sqrt((double)cap * 1.4)));
+    }
     int rc = launch_forward(c, h, w, identity, want_grad, theta_host);
     if (rc) return rc;
     c->pend.active = true; c->pend.ep = ep; c->pend.h = h; c->pend.w = w; c->pend.identity = identity;
@@ -552,7 +571,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     if (const char* s = getenv("EINCM_CHUNK")) { int v = atoi(s); if (v >= NT && v <= MAX_CHUNK) c->chunk = (v / NT) * NT; }
     if (const char* s = getenv("EINCM_SEG")) { int v = atoi(s); if (v >= 64 && v <= MAX_SEG) c->seg = v; }
     if (const char* s = getenv("EINCM_SEG_SPLAT")) { int v = atoi(s); if (v >= 64 && v <= MAX_SEG) c->seg_s = v; }
-    if (const char* s = getenv("EINCM_WINCAP")) { int v = atoi(s); if (v >= 1024 && v <= WIN_CAP_MAX) c->wincap = v; }
+    if (const char* s = getenv("EINCM_WINCAP")) { int v = atoi(s); if (v >= 1024 && v <= 6912) { c->wincap = (v / 4) * 4; c->wincap_fixed = true; } }
     auto bail = [&](const char* what, hipError_t err) -> eincm_ctx* {
         fail(nullptr, EINCM_ERR_HIP, "eincm_create: %s failed: %s", what, hipGetErrorString(err));
         free_all(c);
