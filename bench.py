@@ -173,7 +173,7 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': 'k_splat', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': splat_bytes, 'avg_launch_ms': splat_ms,
-                         'binding_resource': 'lds_atomic',
+                         'binding_resource': 'valu issue (PMC: VALU pipe ~85 % busy, profiles/r01/pmc_valu_counter_collection.csv), then lds_atomic',
                          'lds_atomic_lane_ops_per_clk_per_cu': (9.0 * B * N * R / (splat_ms * 1e-3) / 256 / 2.4e9) if splat_ms > 0 else 0.0,
                          'lds_atomic_peak_lane_ops_per_clk_per_cu': [4.8, 7.4],
                          'lds_atomic_note': '9 ds_add_u32 per warped event; peak = tools/lds_atomic_bench.hip (clustered, distinct addresses), profiles/r01/lds_atomic_microbench.txt'},
