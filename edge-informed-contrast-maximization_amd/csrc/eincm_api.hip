@@ -259,6 +259,8 @@ int ensure_resample(eincm_ctx* c, int h, int w, int method) {
     return EINCM_OK;
 }
 
+constexpr size_t ZERO_COPY_MAX = 16384;   // doubles of theta / gradient that cross PCIe by zero-copy access to pinned host memory
+
 // blocks of the two event kernels: every (segment, reference time) pair, padded to a multiple of 8 segments (block_to_work)
 unsigned event_grid(const eincm_ctx* c) { return (unsigned)(((c->n_items + NXCD - 1) / NXCD) * NXCD * c->g.R); }
 unsigned splat_grid(const eincm_ctx* c) { return (unsigned)(((c->n_items_s + NXCD - 1) / NXCD) * NXCD * c->g.R); }
@@ -269,9 +271,14 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool want_grad, co
     const Geom& g = c->g;
     const size_t nth = (size_t)h * w * 2;
     const bool use_arg = !identity && (size_t)g.B * nth <= (size_t)THETA_ARG_MAX;
+    const double* theta_dev = c->d_theta_in;
     ThetaArg targ;
     if (use_arg) {
         memcpy(targ.v, theta_host, (size_t)g.B * nth * sizeof(double));     // theta rides in the kernel arguments
+    } else if ((size_t)g.B * nth <= ZERO_COPY_MAX) {
+        // medium theta (e.g. 16x16): k_theta reads it straight from the pinned, GPU-mapped staging buffer (no copy command)
+        memcpy(c->h_theta, theta_host, (size_t)g.B * nth * sizeof(double));
+        theta_dev = c->h_theta;
     } else {
         StageTimer t(c, EINCM_STAGE_COPY);
         memcpy(c->h_theta, theta_host, (size_t)g.B * nth * sizeof(double));
@@ -282,7 +289,7 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool want_grad, co
         hipLaunchKernelGGL(k_theta, dim3(g.ntiles, g.B), dim3(NT), 0, c->stream, g, h, w, identity ? 1 : 0, use_arg ? 1 : 0, targ,
                            c->d_iwe, want_grad ? c->d_gTheta : nullptr, (want_grad && !identity) ? c->d_gth : nullptr,
                            (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap,
-                           c->d_theta_in, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_Theta, c->d_tmm);
+                           theta_dev, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_Theta, c->d_tmm);
     }
     {
         StageTimer t(c, EINCM_STAGE_SPLAT);
@@ -387,6 +394,7 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
     if (want_grad && !grad) return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
     int rc = EINCM_OK;
     const bool g2_from_imgrad = want_grad && ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG;
+    const bool zero_copy_out = !identity && (size_t)g.B * nth <= ZERO_COPY_MAX;
     {
         StageTimer t(c, EINCM_STAGE_STATS);
         // Gradient evaluations with the grad-mag contrast take the contrast energy from k_imgrad (which computes the Scharr
@@ -439,16 +447,19 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
     }
     {
         StageTimer t(c, EINCM_STAGE_FINAL);
+        // small results (everything but a dense gradient) are written by k_final straight into pinned host memory: no D2H copy command
         hipLaunchKernelGGL(k_final, dim3(g.B), dim3(NT), 0, c->stream, g, ep, c->d_parts, c->d_divparts, c->d_tvparts,
                            c->d_tmm, c->d_wc, g2_from_imgrad ? c->d_g2parts : nullptr, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap,
-                           c->d_outs, c->d_grad, want_grad ? 1 : 0);
+                           zero_copy_out ? c->h_outs : c->d_outs, zero_copy_out ? c->h_grad : c->d_grad, want_grad ? 1 : 0);
         if (want_grad && identity) {
             hipLaunchKernelGGL(k_final_dense, dim3(256, g.B), dim3(NT), 0, c->stream, g, ep.use_tv_grad, c->d_gTheta,
                                c->d_tvg, c->d_outs, c->d_grad);
         }
     }
     HIPCHK(c, hipGetLastError());
-    if (want_grad && g.B == c->maxB) {      // outs and grad are contiguous: one copy
+    if (zero_copy_out) {
+        // nothing to copy
+    } else if (want_grad && g.B == c->maxB) {      // outs and grad are contiguous: one copy
         HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal) + (size_t)g.B * nth * sizeof(double),
                                  hipMemcpyDeviceToHost, c->stream));
     } else {

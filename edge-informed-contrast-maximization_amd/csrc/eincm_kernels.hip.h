@@ -1264,27 +1264,28 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
 {
     __shared__ double scratch[NWAVE];
     __shared__ double sh_tvscale;
+    __shared__ double sh_rel[3][16];           // per reference time: rel_contrast, rel_corr, rel_div terms
     const int b = blockIdx.x;
     const WinConst& c = wc[b];
     OutScal* __restrict__ o = outs + b;
     const double HW = (double)g.H * (double)g.W;
-    double sum_rel_con = 0.0, sum_rel_corr = 0.0, sum_rel_div = 0.0;     // live in thread 0
-    for (int r = 0; r < g.R; ++r) {
-        double dsum = 0.0;
-        if (ep.want_div) {
-            double v = 0.0;
-            for (int i = threadIdx.x; i < g.ntiles; i += NT) v += divparts[((size_t)b * g.R + r) * g.ntiles + i];
-            dsum = block_sum(v, scratch);
-        }
-        double g2sum = 0.0;
-        if (g2parts) {
-            double v = 0.0;
-            for (int i = threadIdx.x; i < g.ntiles; i += NT) v += g2parts[((size_t)b * g.R + r) * g.ntiles + i];
-            g2sum = block_sum(v, scratch);
-        }
-        if (threadIdx.x < 64) {
+    // one wave per reference time (waves take r = wave, wave + NWAVE, ...): no block-wide barriers inside the loop
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int r = wv; r < g.R; r += NWAVE) {
+            double dsum = 0.0, g2sum = 0.0;
+            if (ep.want_div) {
+                double v = 0.0;
+                for (int i = lane; i < g.ntiles; i += 64) v += divparts[((size_t)b * g.R + r) * g.ntiles + i];
+                dsum = __shfl(wave_sum(v), 0, 64);
+            }
+            if (g2parts) {
+                double v = 0.0;
+                for (int i = lane; i < g.ntiles; i += 64) v += g2parts[((size_t)b * g.R + r) * g.ntiles + i];
+                g2sum = __shfl(wave_sum(v), 0, 64);
+            }
             const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
-            if (threadIdx.x == 0) {
+            if (lane == 0) {
                 const double mse = mse_from_moments(s, c.sE[r], c.sEE[r], HW);
                 const double mean = s.sI / HW;
                 const double var = s.sII / HW - mean * mean;
@@ -1293,12 +1294,16 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
                 const double c0 = (ep.contrast_kind == 1) ? c.c0_var : c.c0_gradmag;
                 const double dv = ep.want_div ? dsum / HW : NAN;
                 o->corr[r] = -mse; o->contrast_gm[r] = cgm; o->var[r] = var; o->div[r] = dv;
-                sum_rel_con += c.mrw[r] * con / (c0 + EPSN);
-                sum_rel_corr += c.mrw[r] * (-mse) / (c.zc[r] + EPSN);
-                if (ep.want_div) sum_rel_div += c.mrw[r] * dv / (c.d0 + EPSN);
+                sh_rel[0][r] = c.mrw[r] * con / (c0 + EPSN);
+                sh_rel[1][r] = c.mrw[r] * (-mse) / (c.zc[r] + EPSN);
+                sh_rel[2][r] = ep.want_div ? c.mrw[r] * dv / (c.d0 + EPSN) : 0.0;
             }
         }
     }
+    __syncthreads();
+    double sum_rel_con = 0.0, sum_rel_corr = 0.0, sum_rel_div = 0.0;     // live in thread 0
+    if (threadIdx.x == 0)
+        for (int r = 0; r < g.R; ++r) { sum_rel_con += sh_rel[0][r]; sum_rel_corr += sh_rel[1][r]; sum_rel_div += sh_rel[2][r]; }
     double tv = 0.0, tvscale = 0.0;
     if (ep.want_tv) {
         double a = 0.0, n = 0.0;
