@@ -339,8 +339,14 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     if (p->contrast_kind != EINCM_CONTRAST_GRAD_MAG && p->contrast_kind != EINCM_CONTRAST_VARIANCE)
         return fail(c, EINCM_ERR_ARG, "contrast_kind %d unknown", p->contrast_kind);
     if (!identity) {
-        if ((int64_t)nth > c->coarse_cap)
-            return fail(c, EINCM_ERR_ARG, "theta (%d,%d,2) exceeds the coarse capacity of this context", h, w);
+        if ((int64_t)h * w > (int64_t)g.H * g.W)
+            return fail(c, EINCM_ERR_ARG, "theta (%d,%d,2) has more cells than the %dx%d sensor has pixels: not supported", h, w, g.H, g.W);
+        if ((int64_t)nth > c->coarse_cap) {          // unusual (the pyramid tops out at 16x16): grow the coarse accumulators
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->d_gth) { (void)hipFree(c->d_gth); c->d_gth = nullptr; }
+            HIPCHK(c, dalloc(&c->d_gth, (size_t)2 * c->maxB * nth));
+            c->coarse_cap = (int64_t)nth;
+        }
         int rc = ensure_resample(c, h, w, p->method);
         if (rc) return rc;
     }

@@ -127,6 +127,65 @@ def test_delta_term_gradient(hw, ck):
         assert a[0]['mean_rel_iwe_divergence'] == pytest.approx(aux['mean_rel_iwe_divergence'], rel=TOL)
 
 
+def test_sixteen_reference_times():
+    """EINCM_MAX_REFS = 16 reference images per window."""
+    H, W, N, R = 64, 96, 12000, 16
+    win = synth.make_window(14, (H, W), N, R, flow='smooth', flow_mag=6.0)
+    th = synth.theta_near_truth(14, win, (2, 2))
+    v_ref, g_ref, _ = O.loss_and_grad(th, *win_args(win), 20.0, 35.0, 0.0, 0.0, 3, 5, (H, W))
+    with engine.Engine((H, W), N, max_refs=R) as eng:
+        eng.set_window(*win_args(win))
+        v, g, _ = eng.loss_grad(th, engine.make_params(20.0, 35.0, 0.0, 0.0, 3))
+    assert abs(v[0] - v_ref) <= TOL * abs(v_ref) and rel(g[0], g_ref) <= TOL
+    with pytest.raises(engine.EincmError):
+        engine.Engine((H, W), N, max_refs=17)
+
+
+@pytest.mark.parametrize('hw,method', [((59, 79), 'bilinear'), ((61, 50), 'lanczos3'), ((40, 100), 'cubic')])
+def test_theta_finer_or_mixed_resolution(hw, method):
+    """theta need not be coarser than the sensor: scale_and_translate down-samples with the anti-aliased (widened) kernel
+    (theta_utils.py:25-35); rows have many taps and a tile covers many cells (k_project's LDS / direct paths)."""
+    H, W, N, R = 60, 80, 15000, 2
+    win = synth.make_window(15, (H, W), N, R, flow='smooth', flow_mag=6.0)
+    th = np.random.default_rng(7).normal(0.0, 3.0, hw + (2,))
+    v_ref, g_ref, aux = O.loss_and_grad(th, *win_args(win), 20.0, 35.0, 2.5e-4, 0.0, 0, 5, (H, W), method)
+    with engine.Engine((H, W), N, max_refs=R) as eng:
+        eng.set_window(*win_args(win))
+        v, g, _ = eng.loss_grad(th, engine.make_params(20.0, 35.0, 2.5e-4, 0.0, 0, method))
+        assert rel(eng.scaled_theta()[0], aux['scaled_theta']) <= 1e-12
+    assert abs(v[0] - v_ref) <= TOL * abs(v_ref) and rel(g[0], g_ref) <= TOL
+    if hw == (59, 79):
+        with engine.Engine((H, W), N, max_refs=R) as eng:          # more cells than pixels: refused, not mis-computed
+            eng.set_window(*win_args(win))
+            with pytest.raises(engine.EincmError, match='more cells than'):
+                eng.loss_grad(np.zeros((90, 120, 2)), engine.make_params(20.0, 35.0, 0.0, 0.0, 0))
+
+
+def test_context_lifecycle_and_coexistence():
+    """Contexts can be created and destroyed repeatedly, and two can be alive (and interleaved) on one GPU."""
+    H, W, N, R = 70, 90, 8000, 3
+    wa = synth.make_window(16, (H, W), N, R, flow='constant', flow_mag=5.0)
+    wb = synth.make_window(17, (H, W), N, R, flow='smooth', flow_mag=5.0)
+    tha, thb = synth.theta_near_truth(16, wa, (1, 1)), synth.theta_near_truth(17, wb, (4, 4))
+    p = engine.make_params(20.0, 35.0, 0.0, 0.0, 2)
+    ref = {}
+    for k, (w_, t_) in {'a': (wa, tha), 'b': (wb, thb)}.items():
+        ref[k] = O.loss_and_grad(t_, *win_args(w_), 20.0, 35.0, 0.0, 0.0, 2, 5, (H, W))[:2]
+    for _ in range(12):                       # create / stage / evaluate / destroy
+        with engine.Engine((H, W), N, max_refs=R) as e:
+            e.set_window(*win_args(wa))
+            v, g, _ = e.loss_grad(tha, p)
+            assert abs(v[0] - ref['a'][0]) <= TOL * abs(ref['a'][0])
+    with engine.Engine((H, W), N, max_refs=R) as ea, engine.Engine((H, W), N, max_refs=R) as eb:
+        ea.set_window(*win_args(wa))
+        eb.set_window(*win_args(wb))
+        for _ in range(3):                    # interleaved use must not cross-talk
+            va, ga, _ = ea.loss_grad(tha, p)
+            vb, gb, _ = eb.loss_grad(thb, p)
+            assert abs(va[0] - ref['a'][0]) <= TOL * abs(ref['a'][0]) and rel(ga[0], ref['a'][1]) <= TOL
+            assert abs(vb[0] - ref['b'][0]) <= TOL * abs(ref['b'][0]) and rel(gb[0], ref['b'][1]) <= TOL
+
+
 def test_dense_c3_shape():
     """BASELINE config C3 shape (480x640, dense per-pixel theta, R=3) at a size the oracle finishes in seconds."""
     H, W, N, R = 480, 640, 200000, 3
