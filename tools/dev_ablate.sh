@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 cp edge-informed-contrast-maximization_amd/libeincm_hip.so /tmp/base.so
-for v in s1 s2 s3; do
+for v in base vF; do
   if [ $v != base ]; then cp tools/variants/libeincm_$v.so edge-informed-contrast-maximization_amd/libeincm_hip.so; touch edge-informed-contrast-maximization_amd/libeincm_hip.so; fi
   python - <<PY
 import sys, os; sys.path.insert(0, '.')
