@@ -41,6 +41,15 @@ class ObjectivesOut(C.Structure):
                 ('flow_warp_losses', _A), ('multi_ref_weights', _A), ('variances', _A), ('zero_variance', C.c_double)]
 
 
+class TiledOut(C.Structure):
+    _fields_ = [('n_refs', C.c_int32), ('n_tiles', C.c_int32),
+                ('adaptive_mean_gradient_magnitude', _A), ('adaptive_variance', _A), ('adaptive_mean_squared_error', _A),
+                ('sum_squared_error', _A), ('mean_hadamard_product', _A), ('sum_hadamard_product', _A), ('joint_contrast', _A)]
+
+
+EDT_FORMULATIONS = {'exponential': 0, 'linear': 1, 'linear-bound': 2, 'logarithmic': 3}
+
+
 class Timings(C.Structure):
     _fields_ = [('ms', C.c_float * N_STAGES), ('total_ms', C.c_float)]
 
@@ -73,6 +82,10 @@ SIGNATURES = [
     ('eincm_finish_constants', C.c_int, [_P]),
     ('eincm_iwe_device_ptr', C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     ('eincm_mask_device_ptr', C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    ('eincm_inv_dist_transform', C.c_int, [_P, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_double, _D,
+                                           C.POINTER(C.c_int32)]),
+    ('eincm_gaussian_blur', C.c_int, [_P, _D, C.c_int, C.c_double, _D]),
+    ('eincm_tiled_objectives', C.c_int, [_P, C.c_int, C.c_int, C.POINTER(TiledOut)]),
 ]
 
 _lib = None

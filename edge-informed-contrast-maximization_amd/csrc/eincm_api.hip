@@ -19,6 +19,7 @@
 #include "eincm.h"
 #include "eincm_kernels.hip.h"
 #include "eincm_binning.hip.h"
+#include "eincm_edges.hip.h"
 
 using namespace eincm;
 
@@ -94,6 +95,9 @@ struct eincm_ctx {
     int cur_h = -1, cur_w = -1, cur_method = -1;
     int64_t coarse_cap = 0;        // doubles per window in d_gth halves
 
+    // scratch of the edge-smoothing / tiled-objective entry points (eincm_edges.hip.h), grown on demand
+    DevBuf e_u8, e_g, e_sq, e_misc, e_a, e_b, e_kern, e_out;
+
     // pinned host staging
     double* h_theta = nullptr;     // (B,H,W,2) capacity
     double* h_grad = nullptr;
@@ -108,6 +112,7 @@ struct eincm_ctx {
 
     // last eval bookkeeping
     bool have_eval = false;
+    int last_nparts = 0;           // how many StatParts per image the last evaluation wrote (k_stats vs k_stats_stream)
     // an evaluation split in two halves (eval_begin ... [caller may all-reduce the IWE stack] ... eval_end)
     struct { bool active = false; EvalParams ep{}; int h = 0, w = 0; bool identity = false, want_grad = false, full_aux = false, div_grad = false; } pend;
     bool constants_pending = false;   // staged with EINCM_SW_DEFER_CONSTANTS and not finished yet
@@ -201,6 +206,7 @@ void free_all(eincm_ctx* c) {
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
     F(c->d_divparts); F(c->d_g2parts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
     F(c->d_rowtap); F(c->d_coltap);
+    for (DevBuf* b : {&c->e_u8, &c->e_g, &c->e_sq, &c->e_misc, &c->e_a, &c->e_b, &c->e_kern, &c->e_out}) { F(b->p); b->bytes = 0; }
     auto FH = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
     FH(c->h_theta); FH(c->h_outs); c->h_grad = nullptr; FH(c->h_wc);
     if (c->have_events) {
@@ -413,6 +419,7 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
             hipLaunchKernelGGL(k_stats, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_edges, c->d_parts,
                                g2_from_imgrad ? 0 : 1);
         }
+        c->last_nparts = g.nparts;
     }
 
     if (ep.want_div) {
@@ -1072,6 +1079,134 @@ int eincm_get_count_images(eincm_ctx* c, uint32_t* counts) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(counts, d, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EINCM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SURVEY row f-4 (eincm_edges.hip.h)
+// ---------------------------------------------------------------------------------------------
+static int ensure_buf(eincm_ctx* c, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes) return EINCM_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return EINCM_OK;
+}
+#define ENSURE(c, buf, bytes) do { const int rc_ = ensure_buf((c), (buf), (bytes)); if (rc_ != EINCM_OK) return rc_; } while (0)
+
+int eincm_inv_dist_transform(eincm_ctx* c, const uint8_t* edge_img, int n, int formulation, double alpha, double d_sat,
+                             double* out, int32_t* sqdist) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!edge_img || (!out && !sqdist)) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (n < 1) return fail(c, EINCM_ERR_ARG, "n = %d images", n);
+    if (formulation < EINCM_EDT_EXPONENTIAL || formulation > EINCM_EDT_LOGARITHMIC)
+        return fail(c, EINCM_ERR_ARG, "unknown formulation %d", formulation);
+    if (out && formulation == EINCM_EDT_EXPONENTIAL && !(alpha > 0.0)) return fail(c, EINCM_ERR_ARG, "alpha = %g must be positive", alpha);
+    if (out && formulation == EINCM_EDT_LINEAR_BOUND && !(d_sat > 0.0)) return fail(c, EINCM_ERR_ARG, "d_sat = %g must be positive", d_sat);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int H = c->H, W = c->W;
+    const size_t npix = (size_t)H * W, tot = npix * n;
+    ENSURE(c, c->e_u8, tot); ENSURE(c, c->e_g, tot * 4); ENSURE(c, c->e_sq, tot * 4); ENSURE(c, c->e_misc, (size_t)n * 8);
+    if (out) ENSURE(c, c->e_a, tot * 8);
+    uint32_t* d_misc = static_cast<uint32_t*>(c->e_misc.p);           // [n] edge pixel count | [n] max squared distance
+    HIPCHK(c, hipMemcpyAsync(c->e_u8.p, edge_img, tot, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_misc, 0, (size_t)n * 8, c->stream));
+    const int gx = (W + NT - 1) / NT;
+    hipLaunchKernelGGL(k_edt_cols, dim3(gx, n), dim3(NT), 0, c->stream, H, W, static_cast<const uint8_t*>(c->e_u8.p),
+                       static_cast<uint32_t*>(c->e_g.p), d_misc);
+    hipLaunchKernelGGL(k_edt_rows, dim3(gx, H, n), dim3(NT), 0, c->stream, H, W, static_cast<const uint32_t*>(c->e_g.p),
+                       static_cast<int32_t*>(c->e_sq.p), d_misc + n);
+    HIPCHK(c, hipGetLastError());
+    std::vector<uint32_t> misc((size_t)n * 2);
+    HIPCHK(c, hipMemcpyAsync(misc.data(), d_misc, misc.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i)
+        if (misc[i] == 0) return fail(c, EINCM_ERR_ARG, "edge image %d has no edge pixel: its distance transform is undefined", i);
+    if (sqdist) HIPCHK(c, hipMemcpyAsync(sqdist, c->e_sq.p, tot * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out) {
+        const int nb = (int)std::min<size_t>((npix + NT - 1) / NT, 1024);
+        hipLaunchKernelGGL(k_edt_finish, dim3(nb, n), dim3(NT), 0, c->stream, (int64_t)npix, static_cast<const int32_t*>(c->e_sq.p),
+                           d_misc + n, formulation, alpha, d_sat, static_cast<double*>(c->e_a.p));
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(out, c->e_a.p, tot * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EINCM_OK;
+}
+
+int eincm_gaussian_blur(eincm_ctx* c, const double* src, int n, double sigma, double* dst) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!src || !dst) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (n < 1) return fail(c, EINCM_ERR_ARG, "n = %d images", n);
+    if (!(sigma > 0.0) || !std::isfinite(sigma)) return fail(c, EINCM_ERR_ARG, "sigma = %g must be positive", sigma);
+    // cv::GaussianBlur on CV_64F with ksize = Size(): ksize = cvRound(sigma*4*2 + 1) | 1; cv::getGaussianKernel (sigma > 0 branch)
+    const int taps = (int)std::nearbyint(sigma * 4 * 2 + 1) | 1;
+    const int radius = taps / 2;
+    if (taps > BLUR_MAX_TAPS) return fail(c, EINCM_ERR_UNSUPPORTED, "sigma = %g needs %d taps (> %d)", sigma, taps, BLUR_MAX_TAPS);
+    if (radius >= c->W || radius >= c->H)
+        return fail(c, EINCM_ERR_ARG, "kernel radius %d does not fit the %d x %d sensor (BORDER_REFLECT_101)", radius, c->H, c->W);
+    std::vector<double> k((size_t)taps);
+    double sum = 0.0;
+    for (int i = 0; i < taps; ++i) { const double x = i - (taps - 1) * 0.5; k[i] = std::exp(-0.5 / (sigma * sigma) * x * x); sum += k[i]; }
+    for (double& v : k) v /= sum;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int H = c->H, W = c->W;
+    const size_t tot = (size_t)H * W * n;
+    ENSURE(c, c->e_a, tot * 8); ENSURE(c, c->e_b, tot * 8); ENSURE(c, c->e_kern, (size_t)BLUR_MAX_TAPS * 8);
+    HIPCHK(c, hipMemcpyAsync(c->e_kern.p, k.data(), k.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->e_a.p, src, tot * 8, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((W + NT - 1) / NT, H, n);
+    hipLaunchKernelGGL(k_blur, grid, dim3(NT), 0, c->stream, H, W, 0, radius, static_cast<const double*>(c->e_kern.p),
+                       static_cast<const double*>(c->e_a.p), static_cast<double*>(c->e_b.p));
+    hipLaunchKernelGGL(k_blur, grid, dim3(NT), 0, c->stream, H, W, 1, radius, static_cast<const double*>(c->e_kern.p),
+                       static_cast<const double*>(c->e_b.p), static_cast<double*>(c->e_a.p));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(dst, c->e_a.p, tot * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // k (host vector) stays alive until here
+    return EINCM_OK;
+}
+
+int eincm_tiled_objectives(eincm_ctx* c, int tile_h, int tile_w, eincm_tiled_out* out) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!out) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (!c->staged || !c->have_eval) return fail(c, EINCM_ERR_STATE, "no evaluation yet");
+    Geom g = c->g;
+    g.nparts = c->last_nparts;
+    if (tile_h < 1 || tile_w < 1 || tile_h > g.H || tile_w > g.W)
+        return fail(c, EINCM_ERR_ARG, "tile %d x %d does not fit the %d x %d sensor", tile_h, tile_w, g.H, g.W);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int ntx = g.W / tile_w, nty = g.H / tile_h, ntl = ntx * nty;
+    const size_t n_t = (size_t)g.B * g.R * ntl * 3, n_p = (size_t)g.B * g.R * 3;
+    ENSURE(c, c->e_out, (n_t + n_p) * 8);
+    double* d_t = static_cast<double*>(c->e_out.p);
+    double* d_p = d_t + n_t;
+    HIPCHK(c, hipMemsetAsync(d_p, 0, n_p * 8, c->stream));
+    hipLaunchKernelGGL(k_tiled, dim3(ntl, g.R, g.B), dim3(NT), 0, c->stream, g, tile_h, tile_w, ntx, c->d_iwe, c->d_edges, c->d_parts, d_t);
+    const int nb = std::min((g.H * g.W + NT - 1) / NT, 256);
+    hipLaunchKernelGGL(k_pair_objectives, dim3(nb, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_edges, c->d_parts, d_p);
+    HIPCHK(c, hipGetLastError());
+    std::vector<double> hv(n_t + n_p);
+    HIPCHK(c, hipMemcpyAsync(hv.data(), d_t, hv.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double HW = (double)g.H * g.W;
+    for (int b = 0; b < g.B; ++b) {
+        eincm_tiled_out& o = out[b];
+        memset(&o, 0, sizeof o);
+        o.n_refs = g.R; o.n_tiles = ntl;
+        for (int r = 0; r < g.R; ++r) {
+            const double* t = hv.data() + ((size_t)b * g.R + r) * ntl * 3;
+            for (int k = 0; k < ntl; ++k) {
+                o.adaptive_mean_gradient_magnitude[r] += t[k * 3];
+                o.adaptive_variance[r] += t[k * 3 + 1];
+                o.adaptive_mean_squared_error[r] += t[k * 3 + 2];
+            }
+            const double* q = hv.data() + n_t + ((size_t)b * g.R + r) * 3;
+            o.sum_squared_error[r] = q[0];
+            o.sum_hadamard_product[r] = q[1];
+            o.mean_hadamard_product[r] = q[1] / HW;
+            o.joint_contrast[r] = q[2] / HW;
+        }
+    }
     return EINCM_OK;
 }
 

@@ -205,6 +205,52 @@ class Engine:
             res.append(d)
         return res
 
+    def tiled_objectives(self, tile_size=None):
+        """extract_tiles + compute_adaptive_* and their pairwise siblings (contrast_objectives.py:42-87,
+        correlation_objectives.py:28-130) on the images of the last evaluation; list of dicts of (R,) arrays."""
+        th, tw = (32, 42) if tile_size is None else tile_size        # contrast_objectives.py:56-59
+        out = (L.TiledOut * self.B)()
+        self._check(self._lib.eincm_tiled_objectives(self._ctx, int(th), int(tw), out))
+        res = []
+        for o in out:
+            d = {'n_tiles': int(o.n_tiles)}
+            for k, t in L.TiledOut._fields_:
+                if t is L._A:
+                    d[k] = np.array(getattr(o, k)[:o.n_refs])
+            res.append(d)
+        return res
+
+    # -- the step before the path: edge smoothing (SURVEY f-4) --------------------------------------
+    def inv_dist_transform(self, edge_imgs, formulation='exponential', alpha=6.0, d_sat=6.0, return_sqdist=False):
+        """1 - minmax(f(d)) of the exact Euclidean distance to the nearest edge pixel (img_utils.py:229-233, :236-410).
+        edge_imgs: (n,H,W) or (H,W), non-zero = edge.  Returns float64 (and the int32 squared distances if asked)."""
+        e = np.asarray(edge_imgs)
+        single = e.ndim == 2
+        e = np.ascontiguousarray((e[None] if single else e) != 0).astype(np.uint8)
+        if e.shape[1:] != (self.H, self.W):
+            raise ValueError(f'edge images must be ({self.H},{self.W}), got {e.shape[1:]}')
+        if formulation not in L.EDT_FORMULATIONS:
+            raise NotImplementedError(f'Invalid option: formulation={formulation!r}')      # img_utils.py:383-385
+        out = np.empty(e.shape, dtype=np.float64)
+        sq = np.empty(e.shape, dtype=np.int32) if return_sqdist else None
+        self._check(self._lib.eincm_inv_dist_transform(
+            self._ctx, e.ctypes.data_as(C.POINTER(C.c_uint8)), e.shape[0], L.EDT_FORMULATIONS[formulation], float(alpha),
+            float(d_sat), _dp(out), sq.ctypes.data_as(C.POINTER(C.c_int32)) if return_sqdist else None))
+        if single:
+            out, sq = out[0], (sq[0] if return_sqdist else None)
+        return (out, sq) if return_sqdist else out
+
+    def gaussian_blur(self, imgs, sigma):
+        """cv.GaussianBlur(float64 image, ksize from sigma, BORDER_REFLECT_101) (img_utils.py:210-220)."""
+        a = np.asarray(imgs, dtype=np.float64)
+        single = a.ndim == 2
+        a = np.ascontiguousarray(a[None] if single else a)
+        if a.shape[1:] != (self.H, self.W):
+            raise ValueError(f'images must be ({self.H},{self.W}), got {a.shape[1:]}')
+        out = np.empty_like(a)
+        self._check(self._lib.eincm_gaussian_blur(self._ctx, _dp(a), a.shape[0], float(sigma), _dp(out)))
+        return out[0] if single else out
+
     # -- device images ----------------------------------------------------------------------------
     def iwes(self):
         a = np.empty((self.B, self.R, self.H, self.W), dtype=np.float32)

@@ -5,5 +5,5 @@ import sys
 
 _pkg = importlib.import_module('edge-informed-contrast-maximization_amd')
 sys.modules[__name__] = _pkg
-for _sub in ('synth', '_lib', 'engine', 'losses', 'sharding', 'solver', 'staging', 'config', 'evaluation'):
+for _sub in ('synth', '_lib', 'engine', 'losses', 'sharding', 'solver', 'staging', 'config', 'evaluation', 'edges'):
     sys.modules[f'{__name__}.{_sub}'] = importlib.import_module(f'edge-informed-contrast-maximization_amd.{_sub}')

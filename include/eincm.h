@@ -195,6 +195,41 @@ int eincm_finish_constants(eincm_ctx* ctx);
 int eincm_iwe_device_ptr(eincm_ctx* ctx, void** dptr, int64_t* n_floats);
 int eincm_mask_device_ptr(eincm_ctx* ctx, void** dptr, int64_t* n_bytes);
 
+/* ---- the step that produces `edges`, and the tiled objectives ------------------------------------ */
+#define EINCM_EDT_EXPONENTIAL 0   /* 1 - exp(-d / alpha)        img_utils.py:232, :382 */
+#define EINCM_EDT_LINEAR 1        /* d                          img_utils.py:376       */
+#define EINCM_EDT_LINEAR_BOUND 2  /* min(d, d_sat)              img_utils.py:378       */
+#define EINCM_EDT_LOGARITHMIC 3   /* log(d + 1)                 img_utils.py:380       */
+
+/* Inverse (exponential) distance transform of binary edge images: replaces eincm_inv_exp_dist_transform
+ * (src/utils/img_utils.py:229-233, scipy.ndimage.distance_transform_edt) and RTEF_IEDT.compute_edge_iedt
+ * (img_utils.py:236-410, Meijster transform) - both are  1 - minmax(f(d))  of the exact Euclidean distance d to the
+ * nearest edge pixel.  edge_img (n, H, W) uint8, non-zero = edge, H x W = the context's sensor; out (n, H, W) double;
+ * sqdist (n, H, W) int32 or NULL receives d^2 (integer work: equals the reference's bit for bit).
+ * An image without any edge pixel has no distance transform: EINCM_ERR_ARG. */
+int eincm_inv_dist_transform(eincm_ctx* ctx, const uint8_t* edge_img, int n, int formulation, double alpha, double d_sat,
+                             double* out, int32_t* sqdist);
+
+/* smoothen_edges (img_utils.py:210-220): cv.GaussianBlur of a float64 image with the kernel size derived from sigma
+ * (round(8 sigma + 1) | 1 taps), separable, BORDER_REFLECT_101.  src, dst (n, H, W) double; may alias. */
+int eincm_gaussian_blur(eincm_ctx* ctx, const double* src, int n, double sigma, double* dst);
+
+/* extract_tiles (img_utils.py:105-120) + compute_adaptive_* (contrast_objectives.py:42-87, correlation_objectives.py:105-130)
+ * and their pairwise siblings (correlation_objectives.py:28-102), on the images of the LAST evaluation, per (window, ref):
+ * contrast-type objectives on the raw IWE (as losses.py:70 does), pair-type ones on (edges, min-max-normalised IWE)
+ * (as losses.py:65 does).  Whole tiles only; the ragged remainder is ignored, as in the reference. */
+typedef struct eincm_tiled_out {
+    int32_t n_refs, n_tiles;
+    double adaptive_mean_gradient_magnitude[EINCM_MAX_REFS];
+    double adaptive_variance[EINCM_MAX_REFS];
+    double adaptive_mean_squared_error[EINCM_MAX_REFS];
+    double sum_squared_error[EINCM_MAX_REFS];
+    double mean_hadamard_product[EINCM_MAX_REFS];
+    double sum_hadamard_product[EINCM_MAX_REFS];
+    double joint_contrast[EINCM_MAX_REFS];
+} eincm_tiled_out;
+int eincm_tiled_objectives(eincm_ctx* ctx, int tile_h, int tile_w, eincm_tiled_out* out /* n_windows */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,12 +38,14 @@ def test_struct_layouts(built_lib, tmp_path):
     import subprocess
     L = importlib.import_module('edge-informed-contrast-maximization_amd._lib')
     src = tmp_path / 'sz.c'
-    src.write_text('#include <stdio.h>\n#include "eincm.h"\nint main(void){printf("%zu %zu %zu %zu\\n",'
-                   'sizeof(eincm_params),sizeof(eincm_aux),sizeof(eincm_timings),sizeof(eincm_objectives_out));return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include "eincm.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n",'
+                   'sizeof(eincm_params),sizeof(eincm_aux),sizeof(eincm_timings),sizeof(eincm_objectives_out),'
+                   'sizeof(eincm_tiled_out));return 0;}\n')
     exe = tmp_path / 'sz'
     subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), '-o', str(exe), str(src)], check=True)
     sizes = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
-    assert sizes == [C.sizeof(L.Params), C.sizeof(L.Aux), C.sizeof(L.Timings), C.sizeof(L.ObjectivesOut)]
+    assert sizes == [C.sizeof(L.Params), C.sizeof(L.Aux), C.sizeof(L.Timings), C.sizeof(L.ObjectivesOut),
+                     C.sizeof(L.TiledOut)]
 
 
 @pytest.mark.parametrize('R', [1, 2, 3, 5, 8])
