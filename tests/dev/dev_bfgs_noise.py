@@ -1,4 +1,4 @@
-import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from functools import partial
 import numpy as np, eincm_amd
 from eincm_amd import losses, solver as sol, synth, engine

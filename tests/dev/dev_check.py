@@ -1,6 +1,6 @@
 """Dev helper (GPU box): HIP engine vs oracle on a few shapes; prints errors and per-stage timings."""
 import os, sys, time, importlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import eincm_amd
 from eincm_amd import engine, synth

@@ -8,7 +8,7 @@ import time
 import numpy as np
 from scipy import ndimage
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 E = importlib.import_module('edge-informed-contrast-maximization_amd.engine')
 from oracle import edge_smoothing as ES           # noqa: E402  (dev tool: oracle as the timed CPU side)
 from tests.test_gpu_edges import _canny_like       # noqa: E402
