@@ -1,0 +1,115 @@
+"""Randomised sweep of the HIP loss/grad path against the fp64 oracle (dev script; run on the GPU box).
+
+Draws sensor sizes, event counts, reference counts, theta shapes, resampling methods, weights, pyramid levels, contrast kinds
+and flow magnitudes (including flows that throw most events out of the frame), batches windows of different sizes in one
+context, and reports the worst relative errors.  usage: python tests/dev/fuzz_gpu.py [n_cases] [seed]
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import eincm_oracle as O    # noqa: E402
+
+pkg = 'edge-informed-contrast-maximization_amd'
+synth = importlib.import_module(pkg + '.synth')
+engine = importlib.import_module(pkg + '.engine')
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def draw_case(rng):
+    H = int(rng.integers(6, 200)); W = int(rng.integers(6, 260))
+    R = int(rng.integers(1, 7))
+    B = int(rng.integers(1, 4))
+    kind = rng.choice(['2dof', 'coarse', 'coarse', 'dense'])
+    if kind == '2dof':
+        hw = (1, 1)
+    elif kind == 'coarse':
+        hw = (int(rng.integers(1, min(H, 17) + 1)), int(rng.integers(1, min(W, 17) + 1)))
+    else:
+        hw = (H, W)
+    method = 'bilinear' if kind == 'dense' else str(rng.choice(['bilinear', 'lanczos3', 'lanczos5', 'cubic']))
+    mag = float(rng.choice([0.0, 2.0, 10.0, 40.0, 200.0]))
+    return dict(H=H, W=W, R=R, B=B, hw=hw, method=method, mag=mag,
+                N=[int(rng.choice([0, 1, 7, 300, 5000, 40000])) for _ in range(B)],
+                alpha=float(rng.choice([0.0, 20.0, 1.0])), beta=float(rng.choice([0.0, 35.0, 1.0])),
+                gamma=float(rng.choice([0.0, 2.5e-4, 0.1])), delta=float(rng.choice([0.0, 0.0, 0.5])),
+                lvl=int(rng.choice([0, 0, 2, 4])), ck=int(rng.integers(0, 2)), flow=str(rng.choice(['constant', 'smooth', 'zero'])))
+
+
+def run_case(c, seed):
+    H, W, R, B = c['H'], c['W'], c['R'], c['B']
+    rng = np.random.default_rng(seed)
+    wins, thetas = [], []
+    for b in range(B):
+        n = c['N'][b]
+        win = synth.make_window(seed + b, (H, W), max(n, 1), R, flow=c['flow'], flow_mag=max(c['mag'], 1e-3))
+        for k in ('xs', 'ys', 'ts'):
+            win[k] = win[k][:n]
+        wins.append(win)
+        h, w = c['hw']
+        base = win['flow_gt'] if (h, w) == (H, W) else np.broadcast_to(win['flow_gt'].mean(axis=(0, 1)), (h, w, 2))
+        thetas.append(base * rng.uniform(0.5, 1.5, (h, w, 2)) + rng.normal(0, 0.5, (h, w, 2)))
+    thetas = np.stack(thetas)
+    value_only = c['mag'] == 0.0 and c['flow'] == 'zero'      # theta = 0 exactly: the gradient cancels by symmetry (ill-conditioned)
+    if value_only:
+        thetas[:] = 0.0
+    args = lambda w: (w['xs'], w['ys'], w['ts'], w['edges'], w['edge_ts'])   # noqa: E731
+    with engine.Engine((H, W), max(sum(c['N']), 1), max_refs=R, max_windows=B) as eng:
+        eng.set_windows([args(w) for w in wins])
+        v, g, _ = eng.loss_grad(thetas, engine.make_params(c['alpha'], c['beta'], c['gamma'], c['delta'], c['lvl'], c['method'], c['ck']))
+        counts = eng.count_images() if hasattr(eng, 'count_images') else None
+    worst = (0.0, 0.0, True)
+    for b in range(B):
+        v_ref, g_ref, aux = O.loss_and_grad(thetas[b], *args(wins[b]), c['alpha'], c['beta'], c['gamma'], c['delta'], c['lvl'], 5,
+                                            (H, W), c['method'], contrast_kind=c['ck'], return_intermediates=True)
+        ev = abs(v[b] - v_ref) / max(abs(v_ref), 1e-300) if np.isfinite(v_ref) else (0.0 if not np.isfinite(v[b]) else np.inf)
+        if np.isfinite(v_ref) and abs(v_ref) < 1e-12:
+            ev = abs(v[b] - v_ref)
+        gmax = np.abs(g_ref).max()
+        eg = rel(g[b], g_ref) if (np.all(np.isfinite(g_ref)) and gmax > 1e-200) else (0.0 if gmax <= 1e-200 and np.abs(g[b]).max() < 1e-12 else
+                                                                                  (0.0 if not np.all(np.isfinite(g_ref)) else np.inf))
+        ok_cnt = True
+        if counts is not None:
+            Theta = O.scale_theta_to_sensor_size(thetas[b], (H, W), c['method'])
+            for r in range(R):
+                wx, wy = O.per_pix_warp(Theta, wins[b]['xs'], wins[b]['ys'], wins[b]['ts'], wins[b]['edge_ts'][r])
+                ok_cnt &= np.array_equal(counts[b, r], O.rounded_count_image(wx, wy, (H, W)))
+        worst = (max(worst[0], ev), max(worst[1], 0.0 if value_only else eg), worst[2] and ok_cnt)
+    return worst
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed0)
+    bad = 0
+    wv = wg = 0.0
+    for i in range(n):
+        c = draw_case(rng)
+        try:
+            res = run_case(c, 1000 * seed0 + i)
+        except Exception as exc:      # noqa: BLE001
+            print(f'case {i} EXC {type(exc).__name__}: {exc}\n   {c}', flush=True)
+            bad += 1
+            continue
+        if res is None:
+            continue
+        ev, eg, okc = res
+        wv, wg = max(wv, ev), max(wg, eg)
+        flag = '' if (ev <= 1e-5 and eg <= 1e-5 and okc) else '   <-- FAIL'
+        if flag:
+            bad += 1
+        print(f'case {i:3d} v {ev:.2e} g {eg:.2e} counts {"ok" if okc else "DIFF"} {flag}' + (f'\n   {c}' if flag else ''), flush=True)
+    print(f'worst value err {wv:.2e}, worst grad err {wg:.2e}, failures {bad}/{n}')
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
