@@ -373,7 +373,7 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     if (!c->wincap_fixed) {
         double vmax = 0.0;
         const size_t nall = (size_t)g.B * nth;
-        const size_t stride = nall > 65536 ? nall / 65536 : 1;          // dense theta: sample (any capacity is correct)
+        const size_t stride = nall > 8192 ? nall / 8192 : 1;            // dense theta: sample (any capacity is correct; 65536 samples cost 90 us)
         for (size_t i = 0; i < nall; i += stride) { const double a = std::fabs(theta_host[i]); if (a > vmax && std::isfinite(a)) vmax = a; }
         // time span of a typical splat segment: seg_s events out of the average tile population
         const double per_tile = (double)std::max<int64_t>(c->n_events, 1) / ((double)g.B * g.ntiles);
@@ -500,10 +500,18 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
         if (o.nonfinite != 0.0) nonfinite = true;
     }
     if (want_grad) {
-        memcpy(grad, c->h_grad, (size_t)g.B * nth * sizeof(double));
+        // copy out and look for NaN/Inf in the same pass; an integer OR-reduction over the exponent bits vectorises, an
+        // early-exit std::isfinite loop does not (0.6 ms of a 1.8 ms dense-theta evaluation at 480x640)
         const size_t n = (size_t)g.B * nth;
-        for (size_t i = 0; i < n && !nonfinite; ++i)
-            if (!std::isfinite(grad[i])) nonfinite = true;
+        const double* __restrict__ src = c->h_grad;
+        uint64_t bad = 0;
+        for (size_t i = 0; i < n; ++i) {
+            uint64_t u;
+            memcpy(&u, src + i, sizeof u);
+            grad[i] = src[i];
+            bad |= (uint64_t)((u & 0x7ff0000000000000ull) == 0x7ff0000000000000ull);
+        }
+        if (bad) nonfinite = true;
     }
     if (nonfinite) return fail(c, EINCM_ERR_NONFINITE, "loss or gradient is not finite");
     return EINCM_OK;

@@ -25,22 +25,23 @@ __global__ __launch_bounds__(NT) void k_edt_cols(int H, int W, const uint8_t* __
                                                   uint32_t* __restrict__ n_edge)
 {
     const int x = blockIdx.x * NT + threadIdx.x;
-    if (x >= W) return;
     const size_t base = (size_t)blockIdx.y * H * W + x;
     uint32_t d = EDT_INF, cnt = 0;
-    for (int y = 0; y < H; ++y) {
+    const int Hc = (x < W) ? H : 0;                    // lanes beyond the row stay for the wave reduction below
+    for (int y = 0; y < Hc; ++y) {
         const bool e = edge[base + (size_t)y * W] != 0;
         cnt += e;
         d = e ? 0u : min(d + 1u, EDT_INF);
         g[base + (size_t)y * W] = d;
     }
     d = EDT_INF;
-    for (int y = H - 1; y >= 0; --y) {
+    for (int y = Hc - 1; y >= 0; --y) {
         const uint32_t down = g[base + (size_t)y * W];
         d = (down == 0u) ? 0u : min(d + 1u, EDT_INF);
         g[base + (size_t)y * W] = min(down, d);
     }
-    if (cnt) atomicAdd(&n_edge[blockIdx.y], cnt);
+    for (int off = 32; off > 0; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off, 64);   // one atomic per wave, not per thread
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&n_edge[blockIdx.y], cnt);
 }
 
 // grid (ceil(W/NT), H, n).  sq (n,H,W) squared Euclidean distance to the nearest edge pixel; maxsq (n).
@@ -62,9 +63,16 @@ __global__ __launch_bounds__(NT) void k_edt_rows(int H, int W, const uint32_t* _
         }
         sq[((size_t)blockIdx.z * H + blockIdx.y) * W + x] = (int32_t)best;
     }
+    // one atomic per workgroup, and only when it can raise the maximum (same-address atomics serialise at L2)
+    __shared__ uint32_t wmax[NWAVE];
     uint32_t m = best;
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(&maxsq[blockIdx.z], m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < NWAVE; ++i) m = max(m, wmax[i]);
+        if (m > __builtin_nontemporal_load(&maxsq[blockIdx.z])) atomicMax(&maxsq[blockIdx.z], m);
+    }
 }
 
 __device__ __forceinline__ double edt_formulation(double d, int formulation, double alpha, double d_sat) {
