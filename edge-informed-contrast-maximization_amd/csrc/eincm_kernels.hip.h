@@ -234,13 +234,20 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const double* th = theta + (size_t)b * h * w * 2;
     double* Th = Theta + (size_t)b * g.H * g.W * 2;
-    // fused clears: this block's tile of every IWE image and of dL/dTheta; block 0 of each window its coarse accumulators
-    for (int p = threadIdx.x; p < TS * TS; p += NT) {
-        const int y = ty * TS + p / TS, x = tx * TS + p % TS;
-        if (y >= g.H || x >= g.W) continue;
-        const size_t o = (size_t)y * g.W + x;
-        for (int r = 0; r < g.R; ++r) iwe[((size_t)b * g.R + r) * g.H * g.W + o] = 0.0f;
-        if (gTheta) *reinterpret_cast<float2*>(gTheta + ((size_t)b * g.H * g.W + o) * 2) = make_float2(0.0f, 0.0f);
+    // fused clears: the IWE stack and dL/dTheta are cleared as flat arrays, each block taking one contiguous slice with
+    // 16-byte stores (tile-shaped clears were scalar and strided: 20 stores per thread); block 0 of each window clears its
+    // coarse accumulators
+    {
+        const size_t nblk = (size_t)gridDim.x * gridDim.y, blk = (size_t)b * gridDim.x + tile;
+        auto clear_flat = [&](float* __restrict__ base, size_t n) {
+            const size_t n4 = n >> 2, per = (n4 + nblk - 1) / nblk;
+            const size_t lo = blk * per, hi = (lo + per < n4) ? lo + per : n4;
+            float4* __restrict__ q = reinterpret_cast<float4*>(base);
+            for (size_t i = lo + threadIdx.x; i < hi; i += NT) q[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (blk == 0 && threadIdx.x < (n & 3)) base[(n4 << 2) + threadIdx.x] = 0.0f;
+        };
+        clear_flat(iwe, (size_t)g.B * g.R * g.H * g.W);
+        if (gTheta) clear_flat(gTheta, (size_t)g.B * g.H * g.W * 2);
     }
     if (gth && tile == 0) {
         const int n = min(h * w == 1 ? NSLOT11 * SLOT11_STRIDE : h * w * 2, gth_cap);
@@ -554,12 +561,22 @@ __global__ __launch_bounds__(NT) void k_stats_stream(Geom g, const float* __rest
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * n;
     const float* __restrict__ E = edges + ((size_t)b * g.R + r) * n;
     double mn = INFINITY, mx = -INFINITY, cmn = 0.0, cmx = 0.0, sI = 0.0, sII = 0.0, sEI = 0.0;
-    for (size_t i = (size_t)part * NT + threadIdx.x; i < n; i += (size_t)NSPART * NT) {
-        const double v = (double)I[i], e = (double)E[i];
-        if (v < mn) { mn = v; cmn = 1.0; } else if (v == mn) cmn += 1.0;
-        if (v > mx) { mx = v; cmx = 1.0; } else if (v == mx) cmx += 1.0;
+    auto take = [&](float fv, float fe) {          // branch-free: (min, #ties) and (max, #ties) are tracked with selects
+        const double v = (double)fv, e = (double)fe;
+        cmn = (v < mn) ? 1.0 : cmn + (v == mn ? 1.0 : 0.0);
+        cmx = (v > mx) ? 1.0 : cmx + (v == mx ? 1.0 : 0.0);
+        mn = fmin(mn, v); mx = fmax(mx, v);
         sI += v; sII += v * v; sEI += e * v;
+    };
+    // four independent load pairs in flight per trip: with one pair per trip the loop paid a full memory latency 11 times
+    const int npx = (int)n, stride = NSPART * NT;
+    int i = part * NT + (int)threadIdx.x;
+    for (; i + 3 * stride < npx; i += 4 * stride) {
+        const float v0 = I[i], v1 = I[i + stride], v2 = I[i + 2 * stride], v3 = I[i + 3 * stride];
+        const float e0 = E[i], e1 = E[i + stride], e2 = E[i + 2 * stride], e3 = E[i + 3 * stride];
+        take(v0, e0); take(v1, e1); take(v2, e2); take(v3, e3);
     }
+    for (; i < npx; i += stride) take(I[i], E[i]);
     const double wmn = wave_min(mn), wmx = wave_max(mx);
     const double bmn = __shfl(wmn, 0, 64), bmx = __shfl(wmx, 0, 64);
     cmn = wave_sum(mn == bmn ? cmn : 0.0);
