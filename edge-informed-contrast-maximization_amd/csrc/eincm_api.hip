@@ -825,10 +825,11 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             const int sg = pass == 0 ? seg : seg_s;
             std::vector<Item>& dst = pass == 0 ? items : items_s;
             for (int k = 0; k < g.ntiles; ++k) {
-                for (int64_t s = cnt[k]; s < cnt[k + 1]; s += sg) {
+                const int len = balanced_seg_len((int)(cnt[k + 1] - cnt[k]), sg);
+                for (int64_t s = cnt[k]; s < cnt[k + 1]; s += len) {
                     Item it;
                     it.win = b; it.tile = k; it.begin = (int32_t)(base + s);
-                    it.count = (int32_t)std::min<int64_t>(sg, cnt[k + 1] - s);
+                    it.count = (int32_t)std::min<int64_t>(len, cnt[k + 1] - s);
                     double lo = st[it.begin], hi = st[it.begin];
                     for (int q = 1; q < it.count; ++q) { lo = std::min(lo, st[it.begin + q]); hi = std::max(hi, st[it.begin + q]); }
                     it.t_lo = lo; it.t_hi = hi;

@@ -123,9 +123,10 @@ __global__ void k_items(Geom g, int seg, const int32_t* __restrict__ tilecount, 
     if (idx >= g.B * g.ntiles) return;
     const int c = tilecount[idx], base = tilebase[idx];
     int k = itembase[idx];
-    for (int s = 0; s < c; s += seg, ++k) {
+    const int len = balanced_seg_len(c, seg);            // same number of segments as ceil(c/seg) (k_bin_tilescan), equal lengths
+    for (int s = 0; s < c; s += len, ++k) {
         Item it;
-        it.win = idx / g.ntiles; it.tile = idx % g.ntiles; it.begin = base + s; it.count = min(seg, c - s);
+        it.win = idx / g.ntiles; it.tile = idx % g.ntiles; it.begin = base + s; it.count = min(len, c - s);
         it.t_lo = 0.0; it.t_hi = 0.0;
         items[k] = it;
     }

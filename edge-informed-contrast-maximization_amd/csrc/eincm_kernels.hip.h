@@ -33,7 +33,7 @@ constexpr float INV_2PI = 0.15915494309189535f;
 // address pattern (0.33 lane-ops/clk/CU measured, tools/lds_atomic_bench.hip) while ds_add_u32 sustains 5-7.4.
 // One tap is <= 1/(2*pi) = 0.1592 and an item holds <= MAX_CHUNK events, so a window pixel is < 4096*0.1592 = 652
 // < 2^32 / FIX_SCALE = 1024: the integer sum cannot overflow.  Resolution 2^-22 = 2.4e-7 (round to nearest, unbiased).
-constexpr int MAX_CHUNK = 4096;    // events per inner chunk (bounds the u32 sums)
+constexpr int MAX_CHUNK = 16384;   // events per inner chunk (bounds the u32 sums; the fixed-point scale follows the count, fix_shift)
 constexpr int MAX_SEG = 1 << 20;   // events per segment (one window flush per segment and reference time)
 // Per-item scale 2^k, the largest power of two with count * 0.16 * 2^k <= 2^32 (k capped at 30, where the smallest
 // tap 0.0137 still keeps its full fp32 mantissa): k = 23 for 2048 events, 22 for 4096, 30 for <= 25 events — sparse
@@ -42,6 +42,14 @@ __device__ __forceinline__ int fix_shift(int count) {
     const unsigned c = (unsigned)ceilf((float)count * 0.16f);
     const int ceillog2 = (c <= 1u) ? 0 : (32 - __clz(c - 1u));
     return min(30, 32 - ceillog2);
+}
+// A tile's c events are cut into ceil(c/seg) segments of EQUAL length (rounded up to whole workgroup trips), not into
+// seg, seg, ..., remainder: the event kernels' workgroups then finish together instead of leaving a tail of short ones.
+__host__ __device__ __forceinline__ int balanced_seg_len(int c, int seg) {
+    const int nseg = (c + seg - 1) / seg;
+    if (nseg <= 1) return seg;
+    const int len = (((c + nseg - 1) / nseg + 255) / 256) * 256;
+    return len < seg ? len : seg;
 }
 constexpr float EXP_M05 = 0.6065306597126334f;   // exp(-1/2)
 
