@@ -114,7 +114,7 @@ struct eincm_ctx {
     bool have_eval = false;
     int last_nparts = 0;           // how many StatParts per image the last evaluation wrote (k_stats vs k_stats_stream)
     // an evaluation split in two halves (eval_begin ... [caller may all-reduce the IWE stack] ... eval_end)
-    struct { bool active = false; EvalParams ep{}; int h = 0, w = 0; bool identity = false, want_grad = false, full_aux = false, div_grad = false; } pend;
+    struct { bool active = false; bool launched = false; EvalParams ep{}; int h = 0, w = 0; bool identity = false, want_grad = false, full_aux = false, div_grad = false; } pend;
     bool constants_pending = false;   // staged with EINCM_SW_DEFER_CONSTANTS and not finished yet
 };
 
@@ -337,7 +337,7 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     const size_t nth = (size_t)h * w * 2;
     const bool full_aux = (p->flags & EINCM_PF_FULL_AUX) != 0;
     const bool div_grad = (p->delta != 0.0 && want_grad);
-    c->pend.active = false;
+    c->pend.active = false; c->pend.launched = false;
     if (div_grad && !c->d_gdiv) {      // rare path (the reference keeps delta = 0, configs/main.yaml:19): allocate lazily
         HIPCHK(c, dalloc(&c->d_gdiv, (size_t)c->maxB * c->maxR * img));
         HIPCHK(c, dalloc(&c->d_dgparts, (size_t)c->maxB * c->maxR * g.ntiles * 2));
@@ -393,18 +393,17 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     return EINCM_OK;
 }
 
-// Second half: image statistics, dL/dIWE, gather, projection, scalar assembly on whatever is in the IWE stack now.
-int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
+// Second half, part 1: enqueue image statistics, dL/dIWE, gather, projection, scalar assembly (on whatever is in the IWE
+// stack now) and the copy back to pinned memory.  Returns without synchronising.
+int eval_end_launch(eincm_ctx* c) {
     if (!c->pend.active) return fail(c, EINCM_ERR_STATE, "no evaluation in flight");
-    c->pend.active = false;
+    if (c->pend.launched) return EINCM_OK;
     Geom g = c->g;
     const EvalParams ep = c->pend.ep;
     const int h = c->pend.h, w = c->pend.w;
     const bool identity = c->pend.identity, want_grad = c->pend.want_grad, full_aux = c->pend.full_aux, div_grad = c->pend.div_grad;
     const size_t nth = (size_t)h * w * 2;
     const bool timing = (c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)) != 0;
-    if (want_grad && !grad) return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
-    int rc = EINCM_OK;
     const bool g2_from_imgrad = want_grad && ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG;
     const bool zero_copy_out = !identity && (size_t)g.B * nth <= ZERO_COPY_MAX;
     {
@@ -481,8 +480,20 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
             HIPCHK(c, hipMemcpyAsync(c->h_grad, c->d_grad, (size_t)g.B * nth * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     if (timing) { (void)hipEventRecord(c->ev[EINCM_N_STAGES][1], c->stream); c->ev_used[EINCM_N_STAGES] = true; }
+    c->pend.launched = true;
+    return EINCM_OK;
+}
+
+// Second half, part 2: wait for the stream and hand the results over.
+int eval_end_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
+    if (!c->pend.active || !c->pend.launched) return fail(c, EINCM_ERR_STATE, "no evaluation in flight");
+    const Geom& g = c->g;
+    const bool want_grad = c->pend.want_grad;
+    const size_t nth = (size_t)c->pend.h * c->pend.w * 2;
+    if (want_grad && !grad) return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    rc = collect_timings(c);
+    c->pend.active = false; c->pend.launched = false;
+    int rc = collect_timings(c);
     if (rc) return rc;
     c->have_eval = true;
 
@@ -515,6 +526,16 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
     }
     if (nonfinite) return fail(c, EINCM_ERR_NONFINITE, "loss or gradient is not finite");
     return EINCM_OK;
+}
+
+int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
+    if (c->pend.active && c->pend.want_grad && !grad) {
+        c->pend.active = false;
+        return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
+    }
+    const int rc = eval_end_launch(c);
+    if (rc) { c->pend.active = false; c->pend.launched = false; return rc; }
+    return eval_end_collect(c, value, grad, aux);
 }
 
 // The whole evaluation.  theta_host: (B,h,w,2) doubles (already validated).
@@ -966,6 +987,30 @@ int eincm_mask_device_ptr(eincm_ctx* c, void** dptr, int64_t* n_bytes) {
     if (!c->staged) return fail(c, EINCM_ERR_STATE, "no staged windows");
     *dptr = c->d_mask; *n_bytes = (int64_t)c->g.B * c->g.H * c->g.W;
     return EINCM_OK;
+}
+
+int eincm_loss_grad_async(eincm_ctx* c, const double* theta, int h, int w, const eincm_params* p, int want_grad) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!c->staged) return fail(c, EINCM_ERR_STATE, "eincm_loss_grad_async called before eincm_set_windows");
+    if (c->constants_pending) return fail(c, EINCM_ERR_STATE, "window constants are not finished (eincm_finish_constants)");
+    if (!theta || !p) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (h < 1 || w < 1) return fail(c, EINCM_ERR_ARG, "theta shape (%d,%d,2) invalid", h, w);
+    if (p->method < 0 || p->method > EINCM_METHOD_CUBIC) return fail(c, EINCM_ERR_ARG, "method %d unknown", p->method);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = eval_begin(c, theta, h, w, p, want_grad != 0);
+    if (rc) return rc;
+    rc = eval_end_launch(c);
+    if (rc) { c->pend.active = false; c->pend.launched = false; }
+    return rc;
+}
+
+int eincm_loss_grad_wait(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!c->pend.active || !c->pend.launched) return fail(c, EINCM_ERR_STATE, "eincm_loss_grad_wait without eincm_loss_grad_async");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = eval_end_collect(c, value, grad, aux);
+    if (rc && rc != EINCM_ERR_NONFINITE) { c->pend.active = false; c->pend.launched = false; }
+    return rc;
 }
 
 int eincm_loss_grad(eincm_ctx* c, const double* theta, int h, int w, const eincm_params* p, double* value, double* grad, eincm_aux* aux) {
