@@ -207,6 +207,9 @@ def main():
         wn = wins[0]
         with engine.Engine((H, W), N, max_refs=R, max_windows=1, device=dev_index) as e1:
             e1.set_window(wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts'])
+            t_spin = time.perf_counter() + 0.1            # working clocks again after the staging pause
+            while time.perf_counter() < t_spin:
+                e1.loss_grad(theta_at(0)[0], p)
             for k in range(3):
                 e1.loss_grad(theta_at(k)[0], p)
             ts = []
