@@ -82,6 +82,8 @@ def run_case(c, seed):
             for r in range(R):
                 wx, wy = O.per_pix_warp(Theta, wins[b]['xs'], wins[b]['ys'], wins[b]['ts'], wins[b]['edge_ts'][r])
                 ok_cnt &= np.array_equal(counts[b, r], O.rounded_count_image(wx, wy, (H, W)))
+        if os.environ.get('EINCM_FUZZ_VERBOSE'):
+            print(f'   window {b}: N {c["N"][b]} value err {ev:.2e} grad err {eg:.2e} max|g_ref| {np.abs(g_ref).max():.3e} max|g - g_ref| {np.abs(g[b] - g_ref).max():.3e}')
         worst = (max(worst[0], ev), max(worst[1], 0.0 if value_only else eg), worst[2] and ok_cnt)
     return worst
 
