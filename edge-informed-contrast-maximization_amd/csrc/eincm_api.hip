@@ -56,6 +56,7 @@ struct eincm_ctx {
     uint32_t* d_xy = nullptr;      // (maxN) x | y<<16, binned
     double* d_t = nullptr;         // (maxN)
     float* d_tf = nullptr;         // (maxN) fp32 copy of the event times for the fast warp
+    bool all_fast = false;         // this evaluation: every velocity provably within the fast warp's range (host-side bound)
     int fastwarp = 1;              // EINCM_FASTWARP=0 turns the fp32 fast path of the warp off (the kernels decide per tile)
     Item* d_items = nullptr;       // (max_items) segments walked by k_gather / k_count / k_mask
     Item* d_items_s = nullptr;     // (max_items) shorter segments walked by k_splat
@@ -306,9 +307,13 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool want_grad, co
             const int lds_multi = (c->seg_s_used > c->chunk) ? 1 : 0;      // segments longer than a chunk need the f32 commit window
             const size_t lds_bytes = (size_t)(lds_multi ? 2 : 1) * g.wincap * sizeof(float)
                                    + (theta_mode == THETA_TILE ? TS * TS * sizeof(double2) : 0);
-            hipLaunchKernelGGL(k_splat, dim3(splat_grid(c)), dim3(NT), lds_bytes, c->stream, g, c->n_items_s, c->chunk, theta_mode, lds_multi,
-                               c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe, c->d_tf,
-                               c->fastwarp ? 1 : 0);
+#define SPLAT_ARGS dim3(splat_grid(c)), dim3(NT), lds_bytes, c->stream, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
+                   c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe, c->d_tf, c->fastwarp ? 1 : 0
+            // all_fast: the host knows every velocity is within the fast warp's range -> fully specialised kernels
+            if (c->all_fast && theta_mode == THETA_CONST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_CONST, 1>), SPLAT_ARGS);
+            else if (c->all_fast)                          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_TILE, 1>), SPLAT_ARGS);
+            else                                           hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<0, 0>), SPLAT_ARGS);
+#undef SPLAT_ARGS
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -373,6 +378,14 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
 
     // LDS window capacity for this evaluation: the host knows theta, hence the largest displacement a segment can see.
     // Small windows give 8 workgroups per CU; windows too small for the flow push taps onto the slow direct-to-HBM path.
+    {   // |Theta| <= max|theta| for the convex (bilinear) weights and for identity; cubic / Lanczos weights overshoot by < 1.5x
+        double vm = 0.0;
+        const size_t nall = (size_t)g.B * nth;
+        bool fin = theta_host != nullptr && nall <= 65536;          // dense theta: no scan, the kernels decide per tile
+        for (size_t i = 0; fin && i < nall; ++i) { const double a = std::fabs(theta_host[i]); if (!(a <= 1e300)) fin = false; else if (a > vm) vm = a; }
+        const double over = (identity || p->method == EINCM_METHOD_BILINEAR) ? 1.0 : 1.5;
+        c->all_fast = c->fastwarp && fin && vm * over <= 32.0;
+    }
     if (!c->wincap_fixed) {
         double vmax = 0.0;
         const size_t nall = (size_t)g.B * nth;
@@ -444,12 +457,16 @@ int eval_end_launch(eincm_ctx* c) {
         }
         {
             StageTimer t(c, EINCM_STAGE_GATHER);
-            if (c->n_items > 0)
-                hipLaunchKernelGGL(k_gather, dim3(event_grid(c)), dim3(NT),
-                               g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), c->stream,
-                               g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta,
-                               direct11 ? 1 : 0, c->d_gth, (int)c->coarse_cap, direct11 ? THETA_CONST : THETA_TILE, c->d_tf,
-                               c->fastwarp ? 1 : 0);
+            if (c->n_items > 0) {
+#define GATHER_ARGS dim3(event_grid(c)), dim3(NT), \
+                    g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), c->stream, \
+                    g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta, \
+                    direct11 ? 1 : 0, c->d_gth, (int)c->coarse_cap, direct11 ? THETA_CONST : THETA_TILE, c->d_tf, c->fastwarp ? 1 : 0
+                if (c->all_fast && direct11) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_CONST, 1>), GATHER_ARGS);
+                else if (c->all_fast)        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_TILE, 1>), GATHER_ARGS);
+                else                         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<0, 0>), GATHER_ARGS);
+#undef GATHER_ARGS
+            }
         }
         // accumulators: two halves (event gradient | TV gradient), each (maxB, coarse_cap), zeroed by k_theta.
         // 2-DoF theta: k_gather already summed the event gradient into the first half; only the TV image needs projecting.

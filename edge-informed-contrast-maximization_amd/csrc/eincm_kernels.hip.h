@@ -359,6 +359,7 @@ __device__ __forceinline__ bool block_to_work(int n_items, int R, int& item, int
 // A segment is walked in chunks of <= chunk events; each chunk is accumulated in u32 fixed point (exact integer
 // ds_add_u32) and committed into the segment's f32 window; the window is flushed to HBM once per segment.
 // ------------------------------------------------------------------------------------------------
+template <int TM, int FT>
 __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, int theta_mode, int lds_multi,
         const Item* __restrict__ items,
         const uint32_t* __restrict__ ev_xy,    // x | y << 16, binned by (window, tile)
@@ -369,6 +370,8 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
         float* __restrict__ iwe,
         const float* __restrict__ ev_tf, int fast)   // fp32 event times; fast = 1: warp2_fast (2-DoF theta, |theta| <= 32)               // (B,R,H,W), zeroed
 {
+    if (TM != 0) theta_mode = TM;                 // compile-time specialisations: the branches on these fold away
+    if (FT != 0) fast = 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsu[];
     float* ldsf = reinterpret_cast<float*>(ldsu + g.wincap);                       // present only when lds_multi
     double2* thtile = reinterpret_cast<double2*>(ldsu + (lds_multi ? 2 : 1) * g.wincap);   // present only for THETA_TILE
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     double2 vconst = make_double2(0.0, 0.0);
     const double* __restrict__ mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
     const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
-    fast = fast && tile_allows_fast_warp(mm);          // uniform over the workgroup
+    if (FT == 0) fast = fast && tile_allows_fast_warp(mm);          // uniform over the workgroup
     float2* thtile_f = reinterpret_cast<float2*>(thtile);       // fast warp: the tile as fp32 pairs in the same LDS region
     if (theta_mode == THETA_CONST) {
         vconst = make_double2(mm[0], mm[2]);
@@ -934,6 +937,7 @@ __global__ __launch_bounds__(NT) void k_divgrad(Geom g, const float* __restrict_
 // The G window is staged in LDS with the same bounding box as the forward; per-pixel sums are accumulated in an
 // LDS copy of the source tile and flushed row-wise.
 // ------------------------------------------------------------------------------------------------
+template <int TM, int FT>
 __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
         const double* __restrict__ Theta, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
@@ -942,6 +946,8 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         int direct11, double* __restrict__ gth_main, int gth_cap,   // 2-DoF theta: sum straight into dL/dtheta (B,gth_cap)
         int theta_mode, const float* __restrict__ ev_tf, int fast)
 {
+    if (TM != 0) theta_mode = TM;
+    if (FT != 0) fast = 1;
     // LDS: [G window: wincap floats][accum: TS*TS*2 doubles unless direct11][Theta tile: TS*TS double2 if THETA_TILE]
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red11[NWAVE];
@@ -969,7 +975,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     double2 vconst = make_double2(0.0, 0.0);
     const double* __restrict__ mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
     const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
-    fast = fast && tile_allows_fast_warp(mm);          // uniform over the workgroup
+    if (FT == 0) fast = fast && tile_allows_fast_warp(mm);          // uniform over the workgroup
     float2* thtile_f = reinterpret_cast<float2*>(thtile);
     if (theta_mode == THETA_CONST) {
         vconst = make_double2(mm[0], mm[2]);
