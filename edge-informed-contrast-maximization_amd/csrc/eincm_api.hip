@@ -55,9 +55,6 @@ struct eincm_ctx {
     // device buffers
     uint32_t* d_xy = nullptr;      // (maxN) x | y<<16, binned
     double* d_t = nullptr;         // (maxN)
-    float* d_tf = nullptr;         // (maxN) fp32 copy of the event times for the fast warp
-    bool all_fast = false;         // this evaluation: every velocity provably within the fast warp's range (host-side bound)
-    int fastwarp = 1;              // EINCM_FASTWARP=0 turns the fp32 fast path of the warp off (the kernels decide per tile)
     Item* d_items = nullptr;       // (max_items) segments walked by k_gather / k_count / k_mask
     Item* d_items_s = nullptr;     // (max_items) shorter segments walked by k_splat
     int n_items_s = 0; int seg_s = 0; int seg_s_used = 0;
@@ -204,7 +201,7 @@ void multi_ref_weights(int R, double* w) {
 
 void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(c->d_xy); F(c->d_t); F(c->d_tf); F(c->d_items); F(c->d_items_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
+    F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_items_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
     F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
     F(c->d_divparts); F(c->d_g2parts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
@@ -308,11 +305,9 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool want_grad, co
             const size_t lds_bytes = (size_t)(lds_multi ? 2 : 1) * g.wincap * sizeof(float)
                                    + (theta_mode == THETA_TILE ? TS * TS * sizeof(double2) : 0);
 #define SPLAT_ARGS dim3(splat_grid(c)), dim3(NT), lds_bytes, c->stream, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
-                   c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe, c->d_tf, c->fastwarp ? 1 : 0
-            // all_fast: the host knows every velocity is within the fast warp's range -> fully specialised kernels
-            if (c->all_fast && theta_mode == THETA_CONST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_CONST, 1>), SPLAT_ARGS);
-            else if (c->all_fast)                          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_TILE, 1>), SPLAT_ARGS);
-            else                                           hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<0, 0>), SPLAT_ARGS);
+                   c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe
+            if (theta_mode == THETA_CONST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_CONST>), SPLAT_ARGS);
+            else                           hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_TILE>), SPLAT_ARGS);
 #undef SPLAT_ARGS
         }
     }
@@ -378,14 +373,6 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
 
     // LDS window capacity for this evaluation: the host knows theta, hence the largest displacement a segment can see.
     // Small windows give 8 workgroups per CU; windows too small for the flow push taps onto the slow direct-to-HBM path.
-    {   // |Theta| <= max|theta| for the convex (bilinear) weights and for identity; cubic / Lanczos weights overshoot by < 1.5x
-        double vm = 0.0;
-        const size_t nall = (size_t)g.B * nth;
-        bool fin = theta_host != nullptr && nall <= 65536;          // dense theta: no scan, the kernels decide per tile
-        for (size_t i = 0; fin && i < nall; ++i) { const double a = std::fabs(theta_host[i]); if (!(a <= 1e300)) fin = false; else if (a > vm) vm = a; }
-        const double over = (identity || p->method == EINCM_METHOD_BILINEAR) ? 1.0 : 1.5;
-        c->all_fast = c->fastwarp && fin && vm * over <= 32.0;
-    }
     if (!c->wincap_fixed) {
         double vmax = 0.0;
         const size_t nall = (size_t)g.B * nth;
@@ -461,10 +448,9 @@ int eval_end_launch(eincm_ctx* c) {
 #define GATHER_ARGS dim3(event_grid(c)), dim3(NT), \
                     g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), c->stream, \
                     g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta, \
-                    direct11 ? 1 : 0, c->d_gth, (int)c->coarse_cap, direct11 ? THETA_CONST : THETA_TILE, c->d_tf, c->fastwarp ? 1 : 0
-                if (c->all_fast && direct11) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_CONST, 1>), GATHER_ARGS);
-                else if (c->all_fast)        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_TILE, 1>), GATHER_ARGS);
-                else                         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<0, 0>), GATHER_ARGS);
+                    direct11 ? 1 : 0, c->d_gth, (int)c->coarse_cap, direct11 ? THETA_CONST : THETA_TILE
+                if (direct11) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_CONST>), GATHER_ARGS);
+                else          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_TILE>), GATHER_ARGS);
 #undef GATHER_ARGS
             }
         }
@@ -661,8 +647,6 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     c->coarse_cap = std::max<int64_t>(64 * 64 * 2, 2);   // coarse theta up to 64x64 (the pyramid tops out at 16x16)
     TRY(dalloc(&c->d_xy, (size_t)max_events_total));
     TRY(dalloc(&c->d_t, (size_t)max_events_total));
-    TRY(dalloc(&c->d_tf, (size_t)max_events_total));
-    if (const char* sf = getenv("EINCM_FASTWARP")) c->fastwarp = atoi(sf);
     TRY(dalloc(&c->d_items, (size_t)c->max_items));
     TRY(dalloc(&c->d_items_s, (size_t)c->max_items));
     c->host_binning = (ntiles > BIN_MAX_TILES) || (getenv("EINCM_HOST_BINNING") != nullptr);
@@ -914,7 +898,6 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->g = g; c->n_items = n_items_total; c->n_items_s = n_items_s_total; c->n_events = N;
     c->win_events.assign(n_events, n_events + n_windows);
-    if (N > 0) hipLaunchKernelGGL(k_cvt_tf, dim3((unsigned)std::min<int64_t>((N + 255) / 256, 4096)), dim3(256), 0, c->stream, (int64_t)N, c->d_t, c->d_tf);
     if (c->n_items > 0) {
         hipLaunchKernelGGL(k_mask, dim3(std::min(c->n_items, 2048)), dim3(NT), 0, c->stream, g, c->d_items, c->n_items, c->d_xy, c->d_mask);
         HIPCHK(c, hipGetLastError());

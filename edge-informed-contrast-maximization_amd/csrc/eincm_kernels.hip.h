@@ -189,29 +189,6 @@ __device__ __forceinline__ void warp_axis(int x, double v, double dt, int& ir, f
     ir = min(max(ri, -(1 << 20)), 1 << 20);          // one v_med3_i32; |w| beyond any sensor (W, H <= 32767): every tap is dropped
 }
 
-// fp32 fast path of the warp for a constant velocity with |v| <= 32 px per unit time: p = v*dt, r = x - rint(p), f = -(p - rint(p)).
-// The error of p is <= 6e-6 px; a lane whose fraction is within 1e-4 of a rounding boundary is redone in fp64 (returns false),
-// so the rounding decisions - the integer part of the result - are exactly those of the fp64 path.
-__device__ __forceinline__ bool warp2_fast(int x, int y, float vxf, float vyf, float dtf, int& irx, int& iry, float& fx, float& fy) {
-    const float px = vxf * dtf, py = vyf * dtf;
-    const float rx = rintf(px), ry = rintf(py);
-    const float ax = px - rx, ay = py - ry;
-    irx = x - (int)rx; iry = y - (int)ry;
-    fx = -ax; fy = -ay;
-    return fmaxf(fabsf(ax), fabsf(ay)) <= 0.5f - 1e-4f;
-}
-
-// The fast warp is exact in its integer part only while |p| = |v*dt| stays small enough for 1e-4 px to dominate the fp32 error:
-// taken per (segment, reference time) when every velocity of the source tile is within 32 px per unit time (NaN -> exact path).
-__device__ __forceinline__ bool tile_allows_fast_warp(const double* __restrict__ mm4) {
-    const double m = fmax(fmax(fabs(mm4[0]), fabs(mm4[1])), fmax(fabs(mm4[2]), fabs(mm4[3])));
-    return m <= 32.0 && mm4[0] == mm4[0] && mm4[2] == mm4[2];
-}
-
-__global__ void k_cvt_tf(int64_t n, const double* __restrict__ t, float* __restrict__ tf) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) tf[i] = (float)t[i];
-}
-
 typedef float f2v __attribute__((ext_vector_type(2)));   // (x-axis value, y-axis value): lowers to v_pk_mul_f32 / v_pk_fma_f32
 
 // Separable 3-tap weights of BOTH axes at once, packed fp32: k(d) = exp(-0.5 (d - f)^2) = exp(-0.5 f^2) exp(d f) exp(-0.5 d^2),
@@ -233,7 +210,7 @@ __device__ __forceinline__ void taps3x2(float fx, float fy, float scale_y, f2v& 
     kp = c * ep;                // d = +1
 }
 
-struct EvReg { uint32_t xy; double t; float tf; };   // one event in flight through the software pipeline of the event kernels
+struct EvReg { uint32_t xy; double t; };   // one event in flight through the software pipeline of the event kernels
 
 // Where an event's velocity Theta[y,x] comes from inside the event kernels.  A per-event global gather costs ~64 L1 cycles per
 // wave-instruction (64 lanes, 64 different cache lines) and was 2/3 of k_splat's time; every workgroup works on ONE source tile, so:
@@ -359,7 +336,7 @@ __device__ __forceinline__ bool block_to_work(int n_items, int R, int& item, int
 // A segment is walked in chunks of <= chunk events; each chunk is accumulated in u32 fixed point (exact integer
 // ds_add_u32) and committed into the segment's f32 window; the window is flushed to HBM once per segment.
 // ------------------------------------------------------------------------------------------------
-template <int TM, int FT>
+template <int TM>      // TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
 __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, int theta_mode, int lds_multi,
         const Item* __restrict__ items,
         const uint32_t* __restrict__ ev_xy,    // x | y << 16, binned by (window, tile)
@@ -367,11 +344,9 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
         const double* __restrict__ Theta,      // (B,H,W,2)
         const double* __restrict__ tmm,        // (B,ntiles,4)
         const double* __restrict__ edge_ts,    // (B,R)
-        float* __restrict__ iwe,
-        const float* __restrict__ ev_tf, int fast)   // fp32 event times; fast = 1: warp2_fast (2-DoF theta, |theta| <= 32)               // (B,R,H,W), zeroed
+        float* __restrict__ iwe)               // (B,R,H,W), zeroed
 {
-    if (TM != 0) theta_mode = TM;                 // compile-time specialisations: the branches on these fold away
-    if (FT != 0) fast = 1;
+    if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsu[];
     float* ldsf = reinterpret_cast<float*>(ldsu + g.wincap);                       // present only when lds_multi
     double2* thtile = reinterpret_cast<double2*>(ldsu + (lds_multi ? 2 : 1) * g.wincap);   // present only for THETA_TILE
@@ -381,20 +356,17 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     const double tau = edge_ts[it.win * g.R + r];
     const int tx0 = (it.tile % g.tilesX) * TS, ty0 = (it.tile / g.tilesX) * TS;
     double2 vconst = make_double2(0.0, 0.0);
-    const double* __restrict__ mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
-    const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
-    if (FT == 0) fast = fast && tile_allows_fast_warp(mm);          // uniform over the workgroup
-    float2* thtile_f = reinterpret_cast<float2*>(thtile);       // fast warp: the tile as fp32 pairs in the same LDS region
     if (theta_mode == THETA_CONST) {
+        const double* mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
         vconst = make_double2(mm[0], mm[2]);
     } else {
+        const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
         for (int p = threadIdx.x; p < TS * TS; p += NT) {
             const int y = ty0 + p / TS, x = tx0 + p % TS;
-            const double2 v = (y < g.H && x < g.W) ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : make_double2(0.0, 0.0);
-            if (fast) thtile_f[p] = make_float2((float)v.x, (float)v.y); else thtile[p] = v;
+            thtile[p] = (y < g.H && x < g.W) ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : make_double2(0.0, 0.0);
         }
     }
-    const Window wn = item_window(g, it, mm, tau);
+    const Window wn = item_window(g, it, tmm + ((size_t)it.win * g.ntiles + it.tile) * 4, tau);
     const int nwin = wn.ww * wn.wh;
     const bool multi = it.count > chunk;
     {   // clear the window(s), 16 B per lane
@@ -417,31 +389,17 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     // Software pipeline over the segment's events, unrolled x3 with renamed register sets (no rotation moves, so no forced
     // vmcnt(0)): the (xy, t) loads of event j+2 are in flight while event j is splatted.
     const int tid = threadIdx.x;
-    const float* __restrict__ etf = ev_tf + it.begin;
-    const float tauf = (float)tau, vxf = (float)vconst.x, vyf = (float)vconst.y;
-    auto load_ev = [&](EvReg& r, int e) {
-        r.xy = 0u; r.t = 0.0; r.tf = 0.0f;
-        if (e < n) { r.xy = exy[e]; if (fast) r.tf = etf[e]; else r.t = et[e]; }
-    };
+    auto load_ev = [&](EvReg& r, int e) { if (e < n) { r.xy = exy[e]; r.t = et[e]; } else { r.xy = 0u; r.t = 0.0; } };
     const float scale_y = INV_2PI * FIX_SCALE;      // single-chunk segments: constant over the loop (re-derived after a commit)
     float scy = scale_y;
-    auto splat_ev = [&](const EvReg& ev, int e) {
+    auto splat_ev = [&](const EvReg& ev) {
+        const double dt = ev.t - tau;
         const int x = ev.xy & 0xffff, y = ev.xy >> 16;
-        int irx, iry; float fx, fy;
-        bool exact = true;
         // tiles start at multiples of TS = 32, so the in-tile index is (y & 31) * 32 + (x & 31)
-        const uint32_t tix = ((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u);
-        if (fast) {
-            const float2 vf = (theta_mode == THETA_CONST) ? make_float2(vxf, vyf) : thtile_f[tix];
-            exact = !warp2_fast(x, y, vf.x, vf.y, ev.tf - tauf, irx, iry, fx, fy);
-        }
-        if (exact) {                                   // always in exact mode; ~2 lanes in 10^4 in fast mode (then from HBM)
-            const double dt = (fast ? et[e] : ev.t) - tau;
-            const double2 v = (theta_mode == THETA_CONST) ? vconst
-                            : fast ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : thtile[tix];
-            warp_axis(x, v.x, dt, irx, fx);
-            warp_axis(y, v.y, dt, iry, fy);
-        }
+        const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)];
+        int irx, iry; float fx, fy;
+        warp_axis(x, v.x, dt, irx, fx);
+        warp_axis(y, v.y, dt, iry, fy);
         f2v km, k0, kp;                              // .x = x-axis weight, .y = y-axis weight (scaled)
         taps3x2(fx, fy, scy, km, k0, kp);
         const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;        // window coords of the top-left tap
@@ -479,7 +437,7 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     auto step = [&](EvReg& cur, EvReg& mid, EvReg& nxt, int j) {
         const int e = j * NT + tid;
         load_ev(nxt, e + 2 * NT);
-        if (e < n) splat_ev(cur, e);
+        if (e < n) splat_ev(cur);
         if (multi && ((j + 1) % ipc == 0 || j + 1 == iters)) {     // chunk boundary (uniform): commit u32 -> f32 window
             __syncthreads();
             for (int i = tid; i < nwin; i += NT) {
@@ -495,7 +453,7 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     EvReg A, B, C;
     load_ev(A, tid);
     load_ev(B, tid + NT);
-    C.xy = 0u; C.t = 0.0; C.tf = 0.0f;
+    C.xy = 0u; C.t = 0.0;
     for (int j = 0; j < iters; j += 3) {
         step(A, B, C, j);
         if (j + 1 < iters) step(B, C, A, j + 1);
@@ -937,17 +895,16 @@ __global__ __launch_bounds__(NT) void k_divgrad(Geom g, const float* __restrict_
 // The G window is staged in LDS with the same bounding box as the forward; per-pixel sums are accumulated in an
 // LDS copy of the source tile and flushed row-wise.
 // ------------------------------------------------------------------------------------------------
-template <int TM, int FT>
+template <int TM>      // TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
 __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
         const double* __restrict__ Theta, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
         const float* __restrict__ G,           // (B,R,H,W)
         float* __restrict__ gTheta,            // (B,H,W,2), zeroed
         int direct11, double* __restrict__ gth_main, int gth_cap,   // 2-DoF theta: sum straight into dL/dtheta (B,gth_cap)
-        int theta_mode, const float* __restrict__ ev_tf, int fast)
+        int theta_mode)
 {
-    if (TM != 0) theta_mode = TM;
-    if (FT != 0) fast = 1;
+    if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
     // LDS: [G window: wincap floats][accum: TS*TS*2 doubles unless direct11][Theta tile: TS*TS double2 if THETA_TILE]
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red11[NWAVE];
@@ -973,17 +930,14 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
     double2 vconst = make_double2(0.0, 0.0);
-    const double* __restrict__ mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
-    const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
-    if (FT == 0) fast = fast && tile_allows_fast_warp(mm);          // uniform over the workgroup
-    float2* thtile_f = reinterpret_cast<float2*>(thtile);
     if (theta_mode == THETA_CONST) {
+        const double* mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
         vconst = make_double2(mm[0], mm[2]);
     } else {
+        const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
         for (int p = threadIdx.x; p < TS * TS; p += NT) {
             const int y = y0 + p / TS, x = x0 + p % TS;
-            const double2 v = (y < g.H && x < g.W) ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : make_double2(0.0, 0.0);
-            if (fast) thtile_f[p] = make_float2((float)v.x, (float)v.y); else thtile[p] = v;
+            thtile[p] = (y < g.H && x < g.W) ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : make_double2(0.0, 0.0);
         }
     }
     __syncthreads();
@@ -993,29 +947,14 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     const int n = it.count;
     const int iters = (n + NT - 1) / NT;
     const int tid = threadIdx.x;
-    const float* __restrict__ etf = ev_tf + it.begin;
-    const float tauf = (float)tau, vxf = (float)vconst.x, vyf = (float)vconst.y;
-    auto load_ev = [&](EvReg& r, int e) {
-        r.xy = 0u; r.t = 0.0; r.tf = 0.0f;
-        if (e < n) { r.xy = exy[e]; if (fast) r.tf = etf[e]; else r.t = et[e]; }
-    };
-    auto gather_ev = [&](const EvReg& ev, int e) {
+    auto load_ev = [&](EvReg& r, int e) { if (e < n) { r.xy = exy[e]; r.t = et[e]; } else { r.xy = 0u; r.t = 0.0; } };
+    auto gather_ev = [&](const EvReg& ev) {
+        const double dt = ev.t - tau;
         const int x = ev.xy & 0xffff, y = ev.xy >> 16;
+        const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)];
         int irx, iry; float fx, fy;
-        bool exact = true;
-        double dt = (double)(ev.tf - tauf);            // fast path: the weight -dt of the event's contribution, 1e-7 relative
-        const uint32_t tix = ((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u);
-        if (fast) {
-            const float2 vf = (theta_mode == THETA_CONST) ? make_float2(vxf, vyf) : thtile_f[tix];
-            exact = !warp2_fast(x, y, vf.x, vf.y, ev.tf - tauf, irx, iry, fx, fy);
-        }
-        if (exact) {
-            dt = (fast ? et[e] : ev.t) - tau;
-            const double2 v = (theta_mode == THETA_CONST) ? vconst
-                            : fast ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : thtile[tix];
-            warp_axis(x, v.x, dt, irx, fx);
-            warp_axis(y, v.y, dt, iry, fy);
-        }
+        warp_axis(x, v.x, dt, irx, fx);
+        warp_axis(y, v.y, dt, iry, fy);
         f2v km, k0, kp;
         taps3x2(fx, fy, INV_2PI, km, k0, kp);
         const float kx[3] = {km.x, k0.x, kp.x}, ky[3] = {km.y, k0.y, kp.y};
@@ -1072,12 +1011,12 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     auto step = [&](EvReg& cur, EvReg& mid, EvReg& nxt, int j) {
         const int e = j * NT + tid;
         load_ev(nxt, e + 2 * NT);
-        if (e < n) gather_ev(cur, e);
+        if (e < n) gather_ev(cur);
     };
     EvReg A, B, C;
     load_ev(A, tid);
     load_ev(B, tid + NT);
-    C.xy = 0u; C.t = 0.0; C.tf = 0.0f;
+    C.xy = 0u; C.t = 0.0;
     for (int j = 0; j < iters; j += 3) {
         step(A, B, C, j);
         if (j + 1 < iters) step(B, C, A, j + 1);

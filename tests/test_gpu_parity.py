@@ -508,10 +508,9 @@ def test_errors():
         assert np.isfinite(v[0])
 
 
-def test_fast_warp_ties_and_boundaries(monkeypatch):
-    """The event kernels warp in fp32 when every velocity of a source tile is <= 32 px per window and redo, in fp64, the lanes
-    whose fraction comes within 1e-4 px of a rounding boundary.  Displacements of exactly k + 1/2 px (ties: half-to-even on
-    x - p, which depends on the parity of x) and just beside them must land on the oracle's pixels."""
+def test_half_pixel_ties_and_near_ties():
+    """Displacements of exactly k + 1/2 px (ties: half-to-even on x - v*dt, which depends on the parity of x) and just beside
+    them must land on the oracle's pixels: a wrong rounding moves a whole 3x3 stamp by one pixel."""
     H, W, R = 64, 96, 2
     rng = np.random.default_rng(4)
     n = 6000
@@ -519,17 +518,17 @@ def test_fast_warp_ties_and_boundaries(monkeypatch):
     ts = rng.choice([0.25, 0.5, 0.75, 1.0], n)                      # exact binary fractions
     order = np.argsort(ts, kind='stable'); xs, ys, ts = xs[order], ys[order], ts[order]
     edges = rng.random((R, H, W)); edge_ts = np.array([0.0, 1.0])
-    for theta in ([2.0, -6.0], [2.0 + 3e-5, -6.0 - 3e-5], [30.0, 31.5], [33.0, -2.0]):     # ties, near-ties, large, beyond the fast range
-        th = np.array(theta).reshape(1, 1, 2)
-        v_ref, g_ref, aux = O.loss_and_grad(th, xs, ys, ts, edges, edge_ts, 20.0, 35.0, 0.0, 0.0, 4, 5, (H, W), return_intermediates=True)
-        outs = {}
-        for fast in ('1', '0'):
-            monkeypatch.setenv('EINCM_FASTWARP', fast)
-            with engine.Engine((H, W), n, max_refs=R) as eng:
-                eng.set_window(xs, ys, ts, edges, edge_ts)
-                v, g, _ = eng.loss_grad(th, engine.make_params(20.0, 35.0, 0.0, 0.0, 4))
-                assert abs(v[0] - v_ref) <= TOL * abs(v_ref), (theta, fast)
-                assert rel(g[0], g_ref) <= TOL, (theta, fast)
-                assert rel(eng.iwes()[0], aux['_iwes']) <= TOL, (theta, fast)
-                outs[fast] = (v[0], g[0])
-        assert outs['1'][0] == pytest.approx(outs['0'][0], rel=2e-6)
+    with engine.Engine((H, W), n, max_refs=R) as eng:
+        eng.set_window(xs, ys, ts, edges, edge_ts)
+        for theta in ([2.0, -6.0], [2.0 + 3e-5, -6.0 - 3e-5], [30.0, 31.5], [33.0, -2.0]):
+            th = np.array(theta).reshape(1, 1, 2)
+            v_ref, g_ref, aux = O.loss_and_grad(th, xs, ys, ts, edges, edge_ts, 20.0, 35.0, 0.0, 0.0, 4, 5, (H, W), return_intermediates=True)
+            v, g, _ = eng.loss_grad(th, engine.make_params(20.0, 35.0, 0.0, 0.0, 4))
+            assert abs(v[0] - v_ref) <= TOL * abs(v_ref), theta
+            assert rel(g[0], g_ref) <= TOL, theta
+            assert rel(eng.iwes()[0], aux['_iwes']) <= TOL, theta
+            Theta = O.scale_theta_to_sensor_size(th, (H, W))
+            cnt = eng.count_images()[0]
+            for r in range(R):
+                wx, wy = O.per_pix_warp(Theta, xs, ys, ts, edge_ts[r])
+                assert np.array_equal(cnt[r], O.rounded_count_image(wx, wy, (H, W))), theta
