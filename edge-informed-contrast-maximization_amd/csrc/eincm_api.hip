@@ -306,8 +306,9 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool want_grad, co
                                    + (theta_mode == THETA_TILE ? TS * TS * sizeof(double2) : 0);
 #define SPLAT_ARGS dim3(splat_grid(c)), dim3(NT), lds_bytes, c->stream, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
                    c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe
-            if (theta_mode == THETA_CONST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_CONST>), SPLAT_ARGS);
-            else                           hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_TILE>), SPLAT_ARGS);
+            if (lds_multi)                      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<0, 1>), SPLAT_ARGS);      // long segments (EINCM_SEG_SPLAT > EINCM_CHUNK)
+            else if (theta_mode == THETA_CONST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_CONST, 0>), SPLAT_ARGS);
+            else                                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_TILE, 0>), SPLAT_ARGS);
 #undef SPLAT_ARGS
         }
     }

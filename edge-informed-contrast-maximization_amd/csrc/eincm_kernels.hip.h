@@ -336,7 +336,7 @@ __device__ __forceinline__ bool block_to_work(int n_items, int R, int& item, int
 // A segment is walked in chunks of <= chunk events; each chunk is accumulated in u32 fixed point (exact integer
 // ds_add_u32) and committed into the segment's f32 window; the window is flushed to HBM once per segment.
 // ------------------------------------------------------------------------------------------------
-template <int TM>      // TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
+template <int TM, int MULTI>   // TM: the theta mode as a compile-time constant (0 = run-time argument); MULTI = 0: no segment is longer than a chunk
 __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, int theta_mode, int lds_multi,
         const Item* __restrict__ items,
         const uint32_t* __restrict__ ev_xy,    // x | y << 16, binned by (window, tile)
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     }
     const Window wn = item_window(g, it, tmm + ((size_t)it.win * g.ntiles + it.tile) * 4, tau);
     const int nwin = wn.ww * wn.wh;
-    const bool multi = it.count > chunk;
+    const bool multi = MULTI != 0 && it.count > chunk;       // MULTI == 0: the commit logic in the loop folds away
     {   // clear the window(s), 16 B per lane
         uint4* z = reinterpret_cast<uint4*>(ldsu);
         const int nq = (nwin + 3) >> 2;
@@ -905,6 +905,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         int theta_mode)
 {
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
+    // (direct11 stays a run-time flag on purpose: folding it as well made this kernel 14 % SLOWER, 132 -> 151 us)
     // LDS: [G window: wincap floats][accum: TS*TS*2 doubles unless direct11][Theta tile: TS*TS double2 if THETA_TILE]
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red11[NWAVE];
