@@ -946,9 +946,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     const uint32_t* __restrict__ exy = ev_xy + it.begin;
     const double* __restrict__ et = ev_t + it.begin;
     const int n = it.count;
-    const int iters = (n + NT - 1) / NT;
     const int tid = threadIdx.x;
-    auto load_ev = [&](EvReg& r, int e) { if (e < n) { r.xy = exy[e]; r.t = et[e]; } else { r.xy = 0u; r.t = 0.0; } };
     auto gather_ev = [&](const EvReg& ev) {
         const double dt = ev.t - tau;
         const int x = ev.xy & 0xffff, y = ev.xy >> 16;
@@ -1008,20 +1006,12 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
             atomicAdd(a + 1, -dt * (double)gwy);
         }
     };
-    // software pipeline with renamed register sets, as in k_splat
-    auto step = [&](EvReg& cur, EvReg& mid, EvReg& nxt, int j) {
-        const int e = j * NT + tid;
-        load_ev(nxt, e + 2 * NT);
-        if (e < n) gather_ev(cur);
-    };
-    EvReg A, B, C;
-    load_ev(A, tid);
-    load_ev(B, tid + NT);
-    C.xy = 0u; C.t = 0.0;
-    for (int j = 0; j < iters; j += 3) {
-        step(A, B, C, j);
-        if (j + 1 < iters) step(B, C, A, j + 1);
-        if (j + 2 < iters) step(C, A, B, j + 2);
+    // a plain strided loop: with 8 waves per SIMD the loads are hidden by occupancy; the renamed-register pipeline of
+    // k_splat measured 2.5 % slower here (133 vs 130 us)
+#pragma unroll 2
+    for (int e = tid; e < n; e += NT) {
+        EvReg ev; ev.xy = exy[e]; ev.t = et[e];
+        gather_ev(ev);
     }
     if (direct11) {
         sum11x = block_sum(sum11x, red11);
