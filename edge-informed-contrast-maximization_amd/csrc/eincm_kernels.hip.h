@@ -462,6 +462,17 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     if (!multi) __syncthreads();
     // row-wise flush: a wave walks one window row -> contiguous fp32 atomics on one image row
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {
+        // the usual case, the window lies inside the image: no index rule per pixel
+        float* __restrict__ dst = img + (size_t)wn.oy * g.W + wn.ox;
+        for (int row = wv; row < wn.wh; row += NWAVE) {
+            for (int col = lane; col < wn.ww; col += 64) {
+                const float v = multi ? ldsf[row * wn.ww + col] : (float)ldsu[row * wn.ww + col] * FIX_INV;
+                if (v != 0.0f) atomicAdd(dst + row * g.W + col, v);
+            }
+        }
+        return;
+    }
     for (int row = wv; row < wn.wh; row += NWAVE) {
         const int gy = wrap_drop(wn.oy + row, g.H);
         if (gy < 0) continue;
@@ -919,11 +930,17 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     const Window wn = item_window(g, it, tmm + ((size_t)it.win * g.ntiles + it.tile) * 4, tau);
     const float* __restrict__ Gi = G + ((size_t)it.win * g.R + r) * g.H * g.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int row = wv; row < wn.wh; row += NWAVE) {
-        const int gy = wrap_drop(wn.oy + row, g.H);
-        for (int col = lane; col < wn.ww; col += 64) {
-            const int gx = wrap_drop(wn.ox + col, g.W);
-            lds[row * wn.ww + col] = (gx >= 0 && gy >= 0) ? Gi[(size_t)gy * g.W + gx] : 0.0f;
+    if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {      // the usual case: window inside the image
+        const float* __restrict__ src = Gi + (size_t)wn.oy * g.W + wn.ox;
+        for (int row = wv; row < wn.wh; row += NWAVE)
+            for (int col = lane; col < wn.ww; col += 64) lds[row * wn.ww + col] = src[row * g.W + col];
+    } else {
+        for (int row = wv; row < wn.wh; row += NWAVE) {
+            const int gy = wrap_drop(wn.oy + row, g.H);
+            for (int col = lane; col < wn.ww; col += 64) {
+                const int gx = wrap_drop(wn.ox + col, g.W);
+                lds[row * wn.ww + col] = (gx >= 0 && gy >= 0) ? Gi[(size_t)gy * g.W + gx] : 0.0f;
+            }
         }
     }
     if (!direct11)
