@@ -109,6 +109,8 @@ struct eincm_ctx {
     bool ev_used[EINCM_N_STAGES + 1];
     bool have_events = false;
     eincm_timings last_t{};
+    eincm_timings sum_t{};         // running sums since the last reset (eincm_get_timings_total)
+    int64_t sum_n = 0;
 
     // last eval bookkeeping
     bool have_eval = false;
@@ -330,6 +332,9 @@ int collect_timings(eincm_ctx* c) {
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev[EINCM_N_STAGES][0], c->ev[EINCM_N_STAGES][1]));
         c->last_t.total_ms = ms;
     }
+    for (int s = 0; s < EINCM_N_STAGES; ++s) c->sum_t.ms[s] += c->last_t.ms[s];
+    c->sum_t.total_ms += c->last_t.total_ms;
+    ++c->sum_n;
     return EINCM_OK;
 }
 
@@ -1272,6 +1277,15 @@ int eincm_tiled_objectives(eincm_ctx* c, int tile_h, int tile_w, eincm_tiled_out
             o.joint_contrast[r] = q[2] / HW;
         }
     }
+    return EINCM_OK;
+}
+
+int eincm_get_timings_total(eincm_ctx* c, eincm_timings* t, int64_t* n_evals, int reset) {
+    if (!c || !t || !n_evals) return EINCM_ERR_ARG;
+    if (!(c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)))
+        return fail(c, EINCM_ERR_STATE, "context was created without EINCM_CF_TIMING / EINCM_CF_TIMING_DOMINANT");
+    *t = c->sum_t; *n_evals = c->sum_n;
+    if (reset) { c->sum_t = eincm_timings{}; c->sum_n = 0; }
     return EINCM_OK;
 }
 

@@ -299,6 +299,14 @@ class Engine:
         self._check(self._lib.eincm_get_scaled_theta(self._ctx, _dp(a)))
         return a
 
+    def timings_total(self, reset=False):
+        """(dict of per-stage ms summed over the evaluations since the last reset, number of evaluations)."""
+        t = L.Timings(); n = C.c_int64(0)
+        self._check(self._lib.eincm_get_timings_total(self._ctx, C.byref(t), C.byref(n), 1 if reset else 0))
+        d = {name: float(t.ms[i]) for i, name in enumerate(L.STAGE_NAMES)}
+        d['total'] = float(t.total_ms)
+        return d, int(n.value)
+
     def timings(self):
         t = L.Timings()
         self._check(self._lib.eincm_get_timings(self._ctx, C.byref(t)))

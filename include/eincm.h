@@ -188,6 +188,9 @@ int eincm_multi_ref_weights(int n_refs, double* w);
 int eincm_resample_matrix(int n_in, int n_out, int method, double* A);
 
 int eincm_get_timings(eincm_ctx* ctx, eincm_timings* t);
+/* sums of the per-evaluation timings since the last reset, and how many evaluations they cover (a bench reads them once after
+ * its timed loop instead of calling eincm_get_timings inside it) */
+int eincm_get_timings_total(eincm_ctx* ctx, eincm_timings* sum, int64_t* n_evals, int reset);
 
 /* Event-sharded evaluation: the events of the SAME windows are split over several contexts (one per GPU);
  * edges and edge_ts are replicated.  The IWE is additive over events (src/utils/event_utils.py:59 is a pure sum), so
