@@ -64,9 +64,10 @@ SIGNATURES = [
     ('eincm_destroy', None, [_P]),
     ('eincm_set_windows', C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int16),
                                     C.POINTER(C.c_int16), _D, _D, _D]),
-    ('eincm_loss_grad', C.c_int, [_P, _D, C.c_int, C.c_int, C.POINTER(Params), _D, _D, C.POINTER(Aux)]),
-    ('eincm_loss_grad_async', C.c_int, [_P, _D, C.c_int, C.c_int, C.POINTER(Params), C.c_int]),
-    ('eincm_loss_grad_wait', C.c_int, [_P, _D, _D, C.POINTER(Aux)]),
+    # the hot calls take raw addresses (c_void_p): ndarray.ctypes.data costs 1 us, data_as(POINTER(c_double)) 2.2 us per argument
+    ('eincm_loss_grad', C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(Params), _P, _P, C.POINTER(Aux)]),
+    ('eincm_loss_grad_async', C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(Params), C.c_int]),
+    ('eincm_loss_grad_wait', C.c_int, [_P, _P, _P, C.POINTER(Aux)]),
     ('eincm_handover_loss_grad', C.c_int, [_P, _D, _D, _D, C.c_int, C.c_int, C.POINTER(Params), _D, _D]),
     ('eincm_objectives', C.c_int, [_P, _D, C.POINTER(ObjectivesOut)]),
     ('eincm_get_iwes', C.c_int, [_P, C.POINTER(C.c_float)]),

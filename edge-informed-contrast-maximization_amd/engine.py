@@ -117,8 +117,8 @@ class Engine:
         value = np.empty(self.B, dtype=np.float64)
         grad = np.empty_like(th) if want_grad else None
         aux = (L.Aux * self.B)() if want_aux else None
-        rc = self._lib.eincm_loss_grad(self._ctx, _dp(th), h, w, C.byref(params), _dp(value),
-                                       _dp(grad) if want_grad else None, aux)
+        rc = self._lib.eincm_loss_grad(self._ctx, th.ctypes.data, h, w, C.byref(params), value.ctypes.data,
+                                       grad.ctypes.data if want_grad else None, aux)
         self._check(rc, allow_nonfinite)
         auxl = None
         if want_aux:
@@ -133,7 +133,7 @@ class Engine:
         if th.ndim != 4 or th.shape[0] != self.B or th.shape[3] != 2:
             raise ValueError(f'theta must be ({self.B},h,w,2), got {th.shape}')
         self._async = (th.shape, bool(want_grad))
-        self._check(self._lib.eincm_loss_grad_async(self._ctx, _dp(th), th.shape[1], th.shape[2], C.byref(params),
+        self._check(self._lib.eincm_loss_grad_async(self._ctx, th.ctypes.data, th.shape[1], th.shape[2], C.byref(params),
                                                     1 if want_grad else 0))
 
     def loss_grad_wait(self, want_aux=False, allow_nonfinite=True):
@@ -141,7 +141,7 @@ class Engine:
         value = np.empty(self.B, dtype=np.float64)
         grad = np.empty(shape, dtype=np.float64) if want_grad else None
         aux = (L.Aux * self.B)() if want_aux else None
-        rc = self._lib.eincm_loss_grad_wait(self._ctx, _dp(value), _dp(grad) if want_grad else None, aux)
+        rc = self._lib.eincm_loss_grad_wait(self._ctx, value.ctypes.data, grad.ctypes.data if want_grad else None, aux)
         self._check(rc, allow_nonfinite)
         auxl = [{k: getattr(a, k) for k, _ in L.Aux._fields_} for a in aux] if want_aux else None
         return value, grad, auxl
