@@ -346,6 +346,8 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     const size_t nth = (size_t)h * w * 2;
     const bool full_aux = (p->flags & EINCM_PF_FULL_AUX) != 0;
     const bool div_grad = (p->delta != 0.0 && want_grad);
+    if (c->pend.active && c->pend.launched)
+        return fail(c, EINCM_ERR_STATE, "an asynchronous evaluation is in flight: call eincm_loss_grad_wait first");
     c->pend.active = false; c->pend.launched = false;
     if (div_grad && !c->d_gdiv) {      // rare path (the reference keeps delta = 0, configs/main.yaml:19): allocate lazily
         HIPCHK(c, dalloc(&c->d_gdiv, (size_t)c->maxB * c->maxR * img));
@@ -719,6 +721,8 @@ void eincm_destroy(eincm_ctx* ctx) {
 
 static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* xs, const int16_t* ys,
                             const double* ts, const double* edges, const double* edge_ts, uint32_t sw_flags) {
+    if (c && c->pend.active && c->pend.launched)
+        return fail(c, EINCM_ERR_STATE, "an asynchronous evaluation is in flight: call eincm_loss_grad_wait first");
     if (!c) return EINCM_ERR_ARG;
     if (n_windows < 1 || n_windows > c->maxB) return fail(c, EINCM_ERR_ARG, "n_windows %d outside 1..%d", n_windows, c->maxB);
     if (n_refs < 1 || n_refs > c->maxR) return fail(c, EINCM_ERR_ARG, "n_refs %d outside 1..%d", n_refs, c->maxR);

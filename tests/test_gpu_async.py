@@ -49,6 +49,10 @@ def test_async_state_errors(built_lib):
         with pytest.raises(engine.EincmError, match='without eincm_loss_grad_async'):
             e.loss_grad_wait()
         e.loss_grad_async(th, p)
+        with pytest.raises(engine.EincmError, match='in flight'):        # nothing else may start on this context before the wait
+            e.loss_grad(th, p)
+        with pytest.raises(engine.EincmError, match='in flight'):
+            e.set_windows(args)
         v1, g1, _ = e.loss_grad_wait()
         v2, g2, _ = e.loss_grad(th, p)                           # the synchronous call still works afterwards
         np.testing.assert_allclose(v1, v2, rtol=1e-6)
