@@ -60,6 +60,8 @@ struct eincm_ctx {
     int n_items_s = 0; int seg_s = 0; int seg_s_used = 0;
     int wincap = WIN_CAP_DEFAULT;
     bool wincap_fixed = false;     // EINCM_WINCAP pins the capacity; otherwise it is chosen per evaluation from max|theta|
+    bool fused11 = true;           // 2-DoF theta: k_gather11 (all reference times of a segment in one workgroup); EINCM_GATHER11=0: k_gather
+    int g11_per_item = 1;          // slots per segment in d_g11 written by the last gather launch
     // device-side staging (eincm_binning.hip.h)
     int16_t* d_raw_x = nullptr; int16_t* d_raw_y = nullptr; double* d_raw_t = nullptr;   // (maxN) events as handed over
     BinBlock* d_binblocks = nullptr; int32_t* d_win_blk = nullptr; uint32_t* d_blockhist = nullptr;
@@ -70,12 +72,17 @@ struct eincm_ctx {
     int64_t max_items = 0;
     float* d_edges = nullptr;      // (B,R,H,W)
     double* d_edge_ts = nullptr;   // (B,R)
-    float* d_iwe = nullptr;        // (B,R,H,W)
+    uint32_t* d_acc = nullptr;     // (B,R,H,W) u32 fixed-point accumulator of the IWE stack; zero between evaluations (consumer-clears)
+    float* d_iwe = nullptr;        // (B,R,H,W) the fp32 IWE stack, written by the statistics pass from d_acc
     float* d_G = nullptr;          // (B,R,H,W)
     float* d_zero_iwe = nullptr;   // (B,H,W)
     double* d_Theta = nullptr;     // (B,H,W,2)
     double* d_theta_in = nullptr;  // (B,H,W,2) capacity (coarse uses a prefix)
-    float* d_gTheta = nullptr;     // (B,H,W,2)
+    long long* d_gTheta = nullptr; // (B,H,W,2) i64 fixed point, zero between evaluations (k_project / k_final_dense clear it)
+    double* d_g11 = nullptr;       // (max_items, R, 2) 2-DoF theta: per-workgroup partials of dL/dtheta (k_gather -> k_final)
+    int32_t* d_win_item0 = nullptr;// (B) first segment of each window in d_items
+    double* d_dtmax = nullptr;     // (B) staging scratch: max |t - tau| per window
+    unsigned* d_gmax = nullptr;    // (B,R) max |dL/dIWE| as float bits (scale of the i64 gradient accumulators)
     double* d_tvg = nullptr;       // (B,H,W,2)
     uint8_t* d_mask = nullptr;     // (B,H,W)
     double* d_tmm = nullptr;       // (B,ntiles,4)
@@ -87,7 +94,7 @@ struct eincm_ctx {
     double* d_tvparts = nullptr;   // (B,ntiles,3)
     WinConst* d_wc = nullptr;      // (B)
     OutScal* d_outs = nullptr;     // (B)
-    double* d_gth = nullptr;       // (2,B,maxcoarse) main | tv accumulators for coarse theta
+    long long* d_gth = nullptr;    // (2,B,maxcoarse) main | tv i64 accumulators for coarse theta, zero between evaluations (k_final clears)
     double* d_grad = nullptr;      // (B,H,W,2) capacity
     double* d_AH = nullptr; double* d_AW = nullptr;     // (H,h) (W,w) capacity H*H, W*W? -> sized on demand
     int2* d_rowtap = nullptr; int2* d_coltap = nullptr;
@@ -114,10 +121,15 @@ struct eincm_ctx {
 
     // last eval bookkeeping
     bool have_eval = false;
+    bool G_valid = false;          // d_G holds dL/dIWE of the last evaluation (eincm_get_count_images borrows the buffer)
     int last_nparts = 0;           // how many StatParts per image the last evaluation wrote (k_stats vs k_stats_stream)
     // an evaluation split in two halves (eval_begin ... [caller may all-reduce the IWE stack] ... eval_end)
     struct { bool active = false; bool launched = false; EvalParams ep{}; int h = 0, w = 0; bool identity = false, want_grad = false, full_aux = false, div_grad = false; } pend;
     bool constants_pending = false;   // staged with EINCM_SW_DEFER_CONSTANTS and not finished yet
+    bool acc_dirty = false;        // a forward half was launched and its consumers were not: accumulators must be memset before reuse
+    bool Theta_valid = false;      // d_Theta holds the upsampled theta of the last evaluation (2-DoF evaluations skip the image)
+    std::vector<double> last_theta11;   // (B,2) theta of the last 2-DoF evaluation (to build d_Theta on demand)
+    int64_t scale_events = 0;      // eincm_set_iwe_scale_events: events per window the u32 accumulator scale must hold (0: the window's own)
 };
 
 namespace {
@@ -204,7 +216,8 @@ void multi_ref_weights(int R, double* w) {
 void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_items_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
-    F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
+    F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_acc); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
+    F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
     F(c->d_divparts); F(c->d_g2parts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
     F(c->d_rowtap); F(c->d_coltap);
@@ -273,12 +286,32 @@ constexpr size_t ZERO_COPY_MAX = 16384;   // doubles of theta / gradient that cr
 unsigned event_grid(const eincm_ctx* c) { return (unsigned)(((c->n_items + NXCD - 1) / NXCD) * NXCD * c->g.R); }
 unsigned splat_grid(const eincm_ctx* c) { return (unsigned)(((c->n_items_s + NXCD - 1) / NXCD) * NXCD * c->g.R); }
 
-// Launch the forward half: theta -> Theta -> IWE stack -> image statistics.
-// theta must already be in d_theta_in (identity: (B,H,W,2); else (B,h,w,2)).
-int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool want_grad, const double* theta_host) {
+// Every cross-workgroup accumulator (u32 IWE stack, i64 dL/dTheta, i64 coarse cells) is zero between evaluations because its
+// consumer clears it.  If a forward half was launched and never consumed (error between the two halves), clear them here.
+int clear_accumulators(eincm_ctx* c) {
+    const size_t img = (size_t)c->H * c->W;
+    HIPCHK(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->maxB * c->maxR * img * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_gTheta, 0, (size_t)c->maxB * img * 2 * sizeof(long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_gth, 0, (size_t)2 * c->maxB * c->coarse_cap * sizeof(long long), c->stream));
+    c->acc_dirty = false;
+    return EINCM_OK;
+}
+
+// theta -> Theta image (+ per-tile velocity bounds) for every window.  theta_dev: (B,h,w,2) on the device or in mapped host memory.
+void launch_theta_image(eincm_ctx* c, int h, int w, bool identity, bool use_arg, const ThetaArg& targ, const double* theta_dev) {
+    const Geom& g = c->g;
+    hipLaunchKernelGGL(k_theta, dim3(g.ntiles, g.B), dim3(NT), 0, c->stream, g, h, w, identity ? 1 : 0, use_arg ? 1 : 0, targ,
+                       theta_dev, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_Theta, c->d_tmm);
+    c->Theta_valid = true;
+}
+
+// Launch the forward half: theta -> Theta -> u32 IWE accumulator.
+// need_theta_image: somebody will read d_Theta (TV term); 2-DoF evaluations otherwise skip the image altogether.
+int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_image, const double* theta_host) {
     const Geom& g = c->g;
     const size_t nth = (size_t)h * w * 2;
     const bool use_arg = !identity && (size_t)g.B * nth <= (size_t)THETA_ARG_MAX;
+    const bool const_theta = !identity && h == 1 && w == 1;
     const double* theta_dev = c->d_theta_in;
     ThetaArg targ;
     if (use_arg) {
@@ -294,20 +327,26 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool want_grad, co
     }
     {
         StageTimer t(c, EINCM_STAGE_THETA);
-        hipLaunchKernelGGL(k_theta, dim3(g.ntiles, g.B), dim3(NT), 0, c->stream, g, h, w, identity ? 1 : 0, use_arg ? 1 : 0, targ,
-                           c->d_iwe, want_grad ? c->d_gTheta : nullptr, (want_grad && !identity) ? c->d_gth : nullptr,
-                           (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap,
-                           theta_dev, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_Theta, c->d_tmm);
+        if (const_theta) {
+            c->last_theta11.assign(theta_host, theta_host + (size_t)g.B * 2);
+            c->Theta_valid = false;
+            if (need_theta_image) launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev);
+            else hipLaunchKernelGGL(k_theta_const, dim3((g.B * g.ntiles + NT - 1) / NT), dim3(NT), 0, c->stream, g, use_arg ? 1 : 0, targ,
+                                    theta_dev, c->d_tmm);
+        } else {
+            launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev);
+        }
     }
     {
         StageTimer t(c, EINCM_STAGE_SPLAT);
+        c->acc_dirty = true;
         if (c->n_items_s > 0) {
-            const int theta_mode = (!identity && h == 1 && w == 1) ? THETA_CONST : THETA_TILE;
+            const int theta_mode = const_theta ? THETA_CONST : THETA_TILE;
             const int lds_multi = (c->seg_s_used > c->chunk) ? 1 : 0;      // segments longer than a chunk need the f32 commit window
             const size_t lds_bytes = (size_t)(lds_multi ? 2 : 1) * g.wincap * sizeof(float)
                                    + (theta_mode == THETA_TILE ? TS * TS * sizeof(double2) : 0);
 #define SPLAT_ARGS dim3(splat_grid(c)), dim3(NT), lds_bytes, c->stream, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
-                   c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_iwe
+                   c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wc, c->d_acc
             if (lds_multi)                      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<0, 1>), SPLAT_ARGS);      // long segments (EINCM_SEG_SPLAT > EINCM_CHUNK)
             else if (theta_mode == THETA_CONST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_CONST, 0>), SPLAT_ARGS);
             else                                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_TILE, 0>), SPLAT_ARGS);
@@ -362,11 +401,13 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (c->d_gth) { (void)hipFree(c->d_gth); c->d_gth = nullptr; }
             HIPCHK(c, dalloc(&c->d_gth, (size_t)2 * c->maxB * nth));
+            HIPCHK(c, hipMemset(c->d_gth, 0, (size_t)2 * c->maxB * nth * sizeof(long long)));
             c->coarse_cap = (int64_t)nth;
         }
         int rc = ensure_resample(c, h, w, p->method);
         if (rc) return rc;
     }
+    if (c->acc_dirty) { const int rcd = clear_accumulators(c); if (rcd) return rcd; }
     for (int s = 0; s <= EINCM_N_STAGES; ++s) c->ev_used[s] = false;
     const bool timing = (c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)) != 0;
     if (timing) { (void)hipEventRecord(c->ev[EINCM_N_STAGES][0], c->stream); }
@@ -394,10 +435,13 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         static const int caps[] = {2304, 3072, 4608, 6912};      // 6912 keeps k_gather's LDS (window + accumulators + Theta tile) under 64 KiB
         int cap = caps[3];
         for (int k = 0; k < 4; ++k) if (need <= caps[k]) { cap = caps[k]; break; }
+        // long splat segments (EINCM_SEG_SPLAT > EINCM_CHUNK) keep a second, f32 window: 2 * cap * 4 B + the 16 KiB Theta tile must
+        // stay within the 64 KiB of dynamic LDS a launch gets without an attribute
+        if (c->seg_s_used > c->chunk) cap = std::min(cap, 4608);
         c->g.wincap = cap;
         c->g.winmaxw = std::max(40, (int)std::lround(std::sqrt((double)cap * 1.4)));
     }
-    int rc = launch_forward(c, h, w, identity, want_grad, theta_host);
+    int rc = launch_forward(c, h, w, identity, ep.want_tv != 0, theta_host);
     if (rc) return rc;
     c->pend.active = true; c->pend.ep = ep; c->pend.h = h; c->pend.w = w; c->pend.identity = identity;
     c->pend.want_grad = want_grad; c->pend.full_aux = full_aux; c->pend.div_grad = div_grad;
@@ -421,11 +465,17 @@ int eval_end_launch(eincm_ctx* c) {
         StageTimer t(c, EINCM_STAGE_STATS);
         // Gradient evaluations with the grad-mag contrast take the contrast energy from k_imgrad (which computes the Scharr
         // images anyway), so the statistics are a pure streaming reduction with NSPART fat partials per image.
+        // Either way the statistics pass is the consumer of the u32 accumulator: it leaves the fp32 IWE stack in d_iwe and the
+        // accumulator zero again.
         if (g2_from_imgrad && g.ntiles >= NSPART) {
             g.nparts = NSPART;
-            hipLaunchKernelGGL(k_stats_stream, dim3(NSPART, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_edges, c->d_parts);
+            hipLaunchKernelGGL(k_stats_stream, dim3(NSPART, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_acc, c->d_iwe, c->d_edges, c->d_wc,
+                               c->d_parts, c->d_gmax);
         } else {
             g.nparts = g.ntiles;
+            const size_t ntot = (size_t)g.B * g.R * g.H * g.W;
+            hipLaunchKernelGGL(k_iwe_finish, dim3((unsigned)std::min<size_t>((ntot + NT - 1) / NT, 2048)), dim3(NT), 0, c->stream, g,
+                               c->d_acc, c->d_iwe, c->d_wc, c->d_gmax);
             hipLaunchKernelGGL(k_stats, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_edges, c->d_parts,
                                g2_from_imgrad ? 0 : 1);
         }
@@ -448,7 +498,7 @@ int eval_end_launch(eincm_ctx* c) {
                 hipLaunchKernelGGL(k_divgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_parts,
                                    c->d_gdiv, c->d_dgparts);
             hipLaunchKernelGGL(k_imgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, ep, c->d_iwe, c->d_edges,
-                               c->d_parts, c->d_wc, c->d_gdiv, c->d_dgparts, c->d_g2parts, c->d_G);
+                               c->d_parts, c->d_wc, c->d_gdiv, c->d_dgparts, c->d_g2parts, c->d_G, c->d_gmax);
         }
         {
             StageTimer t(c, EINCM_STAGE_GATHER);
@@ -456,14 +506,35 @@ int eval_end_launch(eincm_ctx* c) {
 #define GATHER_ARGS dim3(event_grid(c)), dim3(NT), \
                     g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), c->stream, \
                     g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta, \
-                    direct11 ? 1 : 0, c->d_gth, (int)c->coarse_cap, direct11 ? THETA_CONST : THETA_TILE
-                if (direct11) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_CONST>), GATHER_ARGS);
-                else          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_TILE>), GATHER_ARGS);
+                    direct11 ? 1 : 0, c->d_g11, c->d_wc, c->d_gmax, direct11 ? THETA_CONST : THETA_TILE
+                if (direct11 && c->fused11) {
+                    // all reference times of a segment in one workgroup: RF windows of `cap` floats in LDS (cap chosen so that they fit)
+                    const int RF = std::min(g.R, G11_RF);
+                    const int nrg = (g.R + RF - 1) / RF;
+                    const int cap = std::min(g.wincap, (int)(65536 / sizeof(float)) / RF / 4 * 4);
+                    const unsigned grid = (unsigned)(((c->n_items * nrg + NXCD - 1) / NXCD) * NXCD);
+#define G11_ARGS dim3(grid), dim3(NT), (size_t)RF * cap * sizeof(float), c->stream, g, c->n_items, nrg, cap, c->d_items, c->d_xy, c->d_t, \
+                 c->d_tmm, c->d_edge_ts, c->d_G, c->d_g11
+                    switch (RF) {
+                        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather11<1>), G11_ARGS); break;
+                        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather11<2>), G11_ARGS); break;
+                        case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather11<3>), G11_ARGS); break;
+                        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather11<4>), G11_ARGS); break;
+                        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather11<5>), G11_ARGS); break;
+                    }
+#undef G11_ARGS
+                    c->g11_per_item = nrg;
+                } else if (direct11) {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_CONST>), GATHER_ARGS);
+                    c->g11_per_item = g.R;
+                } else {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_TILE>), GATHER_ARGS);
+                }
 #undef GATHER_ARGS
             }
         }
-        // accumulators: two halves (event gradient | TV gradient), each (maxB, coarse_cap), zeroed by k_theta.
-        // 2-DoF theta: k_gather already summed the event gradient into the first half; only the TV image needs projecting.
+        // accumulators: two halves (event gradient | TV gradient), each (maxB, coarse_cap) i64, zero on entry (k_final clears them).
+        // 2-DoF theta: k_gather left per-workgroup partials of the event gradient for k_final; only the TV image needs projecting.
         const int nsrc = (direct11 ? 0 : 1) + (ep.use_tv_grad ? 1 : 0);
         if (!identity && nsrc > 0) {
             StageTimer t(c, EINCM_STAGE_PROJECT);
@@ -477,10 +548,11 @@ int eval_end_launch(eincm_ctx* c) {
         // small results (everything but a dense gradient) are written by k_final straight into pinned host memory: no D2H copy command
         hipLaunchKernelGGL(k_final, dim3(g.B), dim3(NT), 0, c->stream, g, ep, c->d_parts, c->d_divparts, c->d_tvparts,
                            c->d_tmm, c->d_wc, g2_from_imgrad ? c->d_g2parts : nullptr, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap,
+                           c->d_g11, c->d_win_item0, c->n_items, c->g11_per_item, c->d_gmax,
                            zero_copy_out ? c->h_outs : c->d_outs, zero_copy_out ? c->h_grad : c->d_grad, want_grad ? 1 : 0);
         if (want_grad && identity) {
             hipLaunchKernelGGL(k_final_dense, dim3(256, g.B), dim3(NT), 0, c->stream, g, ep.use_tv_grad, c->d_gTheta,
-                               c->d_tvg, c->d_outs, c->d_grad);
+                               c->d_tvg, c->d_wc, c->d_gmax, c->d_outs, c->d_grad);
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -496,6 +568,7 @@ int eval_end_launch(eincm_ctx* c) {
     }
     if (timing) { (void)hipEventRecord(c->ev[EINCM_N_STAGES][1], c->stream); c->ev_used[EINCM_N_STAGES] = true; }
     c->pend.launched = true;
+    c->acc_dirty = false;          // every accumulator this evaluation touched has been consumed (and cleared) by the kernels above
     return EINCM_OK;
 }
 
@@ -505,12 +578,15 @@ int eval_end_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) 
     const Geom& g = c->g;
     const bool want_grad = c->pend.want_grad;
     const size_t nth = (size_t)c->pend.h * c->pend.w * 2;
-    if (want_grad && !grad) return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
+    // The stream is drained before ANY return: the kernels in flight read the pinned theta staging buffer and write the pinned
+    // result block, so the context must not look idle (and accept the next theta) while they run.
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->pend.active = false; c->pend.launched = false;
+    if (want_grad && !grad) return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
     int rc = collect_timings(c);
     if (rc) return rc;
     c->have_eval = true;
+    c->G_valid = want_grad;
 
     bool nonfinite = false;
     for (int b = 0; b < g.B; ++b) {
@@ -545,11 +621,12 @@ int eval_end_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) 
 
 int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
     if (c->pend.active && c->pend.want_grad && !grad) {
+        (void)hipStreamSynchronize(c->stream);       // the forward half is in flight and reads the pinned theta buffer
         c->pend.active = false;
         return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
     }
     const int rc = eval_end_launch(c);
-    if (rc) { c->pend.active = false; c->pend.launched = false; return rc; }
+    if (rc) { (void)hipStreamSynchronize(c->stream); c->pend.active = false; c->pend.launched = false; return rc; }
     return eval_end_collect(c, value, grad, aux);
 }
 
@@ -638,8 +715,10 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     c->cflags = flags;
     if (const char* s = getenv("EINCM_CHUNK")) { int v = atoi(s); if (v >= NT && v <= MAX_CHUNK) c->chunk = (v / NT) * NT; }
     if (const char* s = getenv("EINCM_SEG")) { int v = atoi(s); if (v >= 64 && v <= MAX_SEG) c->seg = v; }
+    if (const char* s = getenv("EINCM_GATHER11")) c->fused11 = atoi(s) != 0;
     if (const char* s = getenv("EINCM_SEG_SPLAT")) { int v = atoi(s); if (v >= 64 && v <= MAX_SEG) c->seg_s = v; }
     if (const char* s = getenv("EINCM_WINCAP")) { int v = atoi(s); if (v >= 1024 && v <= 6912) { c->wincap = (v / 4) * 4; c->wincap_fixed = true; } }
+    if (c->seg_s > c->chunk && c->wincap > 4608) c->wincap = 4608;       // two LDS windows in k_splat's long-segment form
     auto bail = [&](const char* what, hipError_t err) -> eincm_ctx* {
         fail(nullptr, EINCM_ERR_HIP, "eincm_create: %s failed: %s", what, hipGetErrorString(err));
         free_all(c);
@@ -652,7 +731,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     const int tilesX = (W + TS - 1) / TS, tilesY = (H + TS - 1) / TS, ntiles = tilesX * tilesY;
     const size_t B = max_windows, R = max_refs, img = (size_t)H * W;
     c->max_items = (int64_t)B * ntiles + max_events_total / 256 + 1;   // segments are never shorter than 256 events unless a tile is
-    c->coarse_cap = std::max<int64_t>(64 * 64 * 2, 2);   // coarse theta up to 64x64 (the pyramid tops out at 16x16)
+    c->coarse_cap = 64 * 64 * 2;   // coarse theta up to 64x64 (the pyramid tops out at 16x16); grown on demand
     TRY(dalloc(&c->d_xy, (size_t)max_events_total));
     TRY(dalloc(&c->d_t, (size_t)max_events_total));
     TRY(dalloc(&c->d_items, (size_t)c->max_items));
@@ -671,16 +750,24 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
         TRY(dalloc(&c->d_itembase, B * ntiles));
         TRY(dalloc(&c->d_bin_misc, (size_t)8));
         TRY(dalloc(&c->d_edges_raw, B * R * img));
-        TRY(dalloc(&c->d_edge_moments, B * R * 2));
+        TRY(dalloc(&c->d_edge_moments, B * R * EDGE_PARTS * 2));
     }
     TRY(dalloc(&c->d_edges, B * R * img));
     TRY(dalloc(&c->d_edge_ts, B * R));
+    TRY(dalloc(&c->d_acc, B * R * img));
+    TRY(hipMemset(c->d_acc, 0, B * R * img * sizeof(uint32_t)));
     TRY(dalloc(&c->d_iwe, B * R * img));
     TRY(dalloc(&c->d_G, B * R * img));
+    TRY(dalloc(&c->d_g11, (size_t)(c->max_items + NXCD) * R * 2));
+    TRY(dalloc(&c->d_win_item0, B + 1));
+    TRY(dalloc(&c->d_dtmax, B));
+    TRY(dalloc(&c->d_gmax, B * R));
+    TRY(hipMemset(c->d_gmax, 0, B * R * sizeof(unsigned)));
     TRY(dalloc(&c->d_zero_iwe, B * img));
     TRY(dalloc(&c->d_Theta, B * img * 2));
     TRY(dalloc(&c->d_theta_in, B * img * 2));
     TRY(dalloc(&c->d_gTheta, B * img * 2));
+    TRY(hipMemset(c->d_gTheta, 0, B * img * 2 * sizeof(long long)));
     TRY(dalloc(&c->d_tvg, B * img * 2));
     TRY(dalloc(&c->d_mask, B * img));
     TRY(dalloc(&c->d_tmm, B * ntiles * 4));
@@ -700,6 +787,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
         c->h_grad = reinterpret_cast<double*>(hblk + B * sizeof(OutScal));
     }
     TRY(dalloc(&c->d_gth, 2 * B * (size_t)c->coarse_cap));
+    TRY(hipMemset(c->d_gth, 0, 2 * B * (size_t)c->coarse_cap * sizeof(long long)));
     TRY(dalloc(&c->d_rowtap, (size_t)H));
     TRY(dalloc(&c->d_coltap, (size_t)W));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_theta), B * img * 2 * sizeof(double), hipHostMallocDefault));
@@ -736,6 +824,8 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     }
     if (N > c->maxN) return fail(c, EINCM_ERR_ARG, "total events %lld exceed capacity %lld", (long long)N, (long long)c->maxN);
     c->staged = false;
+    c->Theta_valid = false;
+    if (c->acc_dirty) { const int rcd = clear_accumulators(c); if (rcd) return rcd; }
     Geom g{};
     g.H = H; g.W = W; g.R = n_refs; g.B = n_windows;
     g.tilesX = (W + TS - 1) / TS; g.tilesY = (H + TS - 1) / TS; g.ntiles = g.tilesX * g.tilesY;
@@ -760,6 +850,8 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             if (!std::isfinite(edge_ts[b * n_refs + r])) return fail(c, EINCM_ERR_ARG, "edge_ts[%d,%d] is not finite", b, r);
     }
     int n_items_total = 0, n_items_s_total = 0;
+    std::vector<double> dtmax_h((size_t)n_windows, 0.0);
+    std::vector<int32_t> item0_h;                  // host path only
     if (!c->host_binning) {
         // ---- device path: counting sort by (window, source tile) on the GPU (eincm_binning.hip.h) ----
         std::vector<BinBlock> blks;
@@ -781,14 +873,13 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         HIPCHK(c, hipMemcpyAsync(c->d_bin_misc, misc_init, sizeof misc_init, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_win_blk, win_blk.data(), win_blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_edges_raw, edges, (size_t)n_windows * n_refs * img * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_edge_moments, 0, (size_t)n_windows * n_refs * 2 * sizeof(double), c->stream));
-        hipLaunchKernelGGL(k_edges, dim3(32, n_refs, n_windows), dim3(NT), 0, c->stream, g, c->d_edges_raw, c->d_edges, c->d_edge_moments);
+        hipLaunchKernelGGL(k_edges, dim3(EDGE_PARTS, n_refs, n_windows), dim3(NT), 0, c->stream, g, c->d_edges_raw, c->d_edges, c->d_edge_moments);
         if (nblk > 0) {
             HIPCHK(c, hipMemcpyAsync(c->d_binblocks, blks.data(), blks.size() * sizeof(BinBlock), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->d_raw_x, xs, (size_t)N * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->d_raw_y, ys, (size_t)N * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->d_raw_t, ts, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(k_bin_hist, dim3(nblk), dim3(NT), g.ntiles * sizeof(uint32_t), c->stream, g, c->d_binblocks, c->d_raw_x, c->d_raw_y,
+            hipLaunchKernelGGL(k_bin_hist, dim3(nblk), dim3(BIN_NT), g.ntiles * sizeof(uint32_t), c->stream, g, c->d_binblocks, c->d_raw_x, c->d_raw_y,
                                c->d_raw_t, c->d_blockhist, c->d_bin_misc + 2);
         } else {
             HIPCHK(c, hipMemsetAsync(c->d_blockhist, 0, sizeof(uint32_t), c->stream));
@@ -798,7 +889,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         hipLaunchKernelGGL(k_bin_tilescan, dim3(1), dim3(1024), 0, c->stream, M, seg, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_bin_misc);
         HIPCHK(c, hipGetLastError());
         int32_t misc[4];
-        std::vector<double> mom((size_t)n_windows * n_refs * 2);
+        std::vector<double> mom((size_t)n_windows * n_refs * EDGE_PARTS * 2);
         HIPCHK(c, hipMemcpyAsync(misc, c->d_bin_misc, sizeof misc, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(mom.data(), c->d_edge_moments, mom.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -818,13 +909,22 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         n_items_total = misc[1];
         if (n_items_total > c->max_items) return fail(c, EINCM_ERR_ARG, "internal: %d segments exceed capacity", n_items_total);
         for (int b = 0; b < n_windows; ++b)
-            for (int r = 0; r < n_refs; ++r) { c->h_wc[b].sE[r] = mom[((size_t)b * n_refs + r) * 2]; c->h_wc[b].sEE[r] = mom[((size_t)b * n_refs + r) * 2 + 1]; }
+            for (int r = 0; r < n_refs; ++r) {          // the blocks' partials, added in index order
+                double sE = 0.0, sEE = 0.0;
+                for (int k = 0; k < EDGE_PARTS; ++k) { const double* m = &mom[(((size_t)b * n_refs + r) * EDGE_PARTS + k) * 2]; sE += m[0]; sEE += m[1]; }
+                c->h_wc[b].sE[r] = sE; c->h_wc[b].sEE[r] = sEE;
+            }
         if (nblk > 0) {
-            hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(NT), g.ntiles * sizeof(uint32_t), c->stream, g, c->d_binblocks, c->d_raw_x, c->d_raw_y,
+            hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(BIN_NT), g.ntiles * sizeof(uint32_t), c->stream, g, c->d_binblocks, c->d_raw_x, c->d_raw_y,
                                c->d_raw_t, c->d_blockhist, c->d_tilebase, c->d_xy, c->d_t);
             hipLaunchKernelGGL(k_items, dim3((M + 255) / 256), dim3(256), 0, c->stream, g, seg, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_items);
             if (n_items_total > 0)
                 hipLaunchKernelGGL(k_seg_minmax, dim3(std::min(n_items_total, 4096)), dim3(NT), 0, c->stream, n_items_total, c->d_items, c->d_t);
+            // per window: first segment and max |t - tau| (needs the segment time ranges and the FIRST segmentation's itembase)
+            HIPCHK(c, hipMemcpyAsync(c->d_edge_ts, edge_ts, (size_t)n_windows * n_refs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_win_consts, dim3(n_windows), dim3(NT), 0, c->stream, g, n_items_total, c->d_items, c->d_itembase, c->d_edge_ts,
+                               c->d_win_item0, c->d_dtmax);
+            HIPCHK(c, hipMemcpyAsync(dtmax_h.data(), c->d_dtmax, (size_t)n_windows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             // second segmentation of the same binned events for k_splat
             hipLaunchKernelGGL(k_bin_tilescan, dim3(1), dim3(1024), 0, c->stream, M, seg_s, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_bin_misc);
             HIPCHK(c, hipMemcpyAsync(misc, c->d_bin_misc, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -835,6 +935,8 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             if (n_items_s_total > 0)
                 hipLaunchKernelGGL(k_seg_minmax, dim3(std::min(n_items_s_total, 4096)), dim3(NT), 0, c->stream, n_items_s_total, c->d_items_s, c->d_t);
             HIPCHK(c, hipGetLastError());
+        } else {
+            HIPCHK(c, hipMemsetAsync(c->d_win_item0, 0, (size_t)(n_windows + 1) * sizeof(int32_t), c->stream));
         }
     } else {
     // ---- host path (sensors with more tiles than the LDS histogram holds, or EINCM_HOST_BINNING=1): stable counting sort ----
@@ -847,7 +949,9 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         const int64_t n = n_events[b];
         const int16_t* x = xs + base; const int16_t* y = ys + base; const double* t = ts + base;
         std::fill(cnt.begin(), cnt.end(), 0);
+        item0_h.push_back((int32_t)items.size());
         for (int64_t i = 0; i < n; ++i) {
+            for (int r = 0; r < n_refs; ++r) dtmax_h[b] = std::max(dtmax_h[b], std::fabs(t[i] - edge_ts[b * n_refs + r]));
             if (x[i] < 0 || x[i] >= W || y[i] < 0 || y[i] >= H)
                 return fail(c, EINCM_ERR_ARG, "event %lld of window %d at (x=%d, y=%d) outside the %dx%d sensor",
                             (long long)i, b, (int)x[i], (int)y[i], H, W);
@@ -903,6 +1007,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         HIPCHK(c, hipMemcpyAsync(c->d_items, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
     if (!items_s.empty())
         HIPCHK(c, hipMemcpyAsync(c->d_items_s, items_s.data(), items_s.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_win_item0, item0_h.data(), item0_h.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_edges, ef.data(), ef.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));     // host vectors go out of scope
     }
@@ -922,6 +1027,11 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         WinConst& wc = c->h_wc[b];
         wc.c0_gradmag = 1.0; wc.c0_var = 1.0; wc.d0 = 1.0;
         for (int r = 0; r < n_refs; ++r) wc.zc[r] = 1.0;
+        // scales of the integer accumulators: the u32 IWE stack must hold every event that may land in it (all shards of an
+        // event-sharded window: eincm_set_iwe_scale_events), the i64 gradient sums this context's own events
+        wc.nev = (double)std::max<int64_t>(n_events[b], 1);
+        wc.gshift = iwe_shift((double)std::max<int64_t>(c->scale_events > 0 ? c->scale_events : n_events[b], 1));
+        wc.dtmax = dtmax_h[b];
     }
     HIPCHK(c, hipMemcpyAsync(c->d_wc, c->h_wc, (size_t)n_windows * sizeof(WinConst), hipMemcpyHostToDevice, c->stream));
     c->staged = true;
@@ -995,10 +1105,17 @@ int eincm_finish_constants(eincm_ctx* c) {
     return rc2;
 }
 
-int eincm_iwe_device_ptr(eincm_ctx* c, void** dptr, int64_t* n_floats) {
-    if (!c || !dptr || !n_floats) return EINCM_ERR_ARG;
+int eincm_iwe_device_ptr(eincm_ctx* c, void** dptr, int64_t* n_words) {
+    if (!c || !dptr || !n_words) return EINCM_ERR_ARG;
     if (!c->staged) return fail(c, EINCM_ERR_STATE, "no staged windows");
-    *dptr = c->d_iwe; *n_floats = (int64_t)c->g.B * c->g.R * c->g.H * c->g.W;
+    *dptr = c->d_acc; *n_words = (int64_t)c->g.B * c->g.R * c->g.H * c->g.W;
+    return EINCM_OK;
+}
+
+int eincm_set_iwe_scale_events(eincm_ctx* c, int64_t n_events_per_window) {
+    if (!c) return EINCM_ERR_ARG;
+    if (n_events_per_window < 0) return fail(c, EINCM_ERR_ARG, "n_events_per_window negative");
+    c->scale_events = n_events_per_window;
     return EINCM_OK;
 }
 
@@ -1020,7 +1137,7 @@ int eincm_loss_grad_async(eincm_ctx* c, const double* theta, int h, int w, const
     int rc = eval_begin(c, theta, h, w, p, want_grad != 0);
     if (rc) return rc;
     rc = eval_end_launch(c);
-    if (rc) { c->pend.active = false; c->pend.launched = false; }
+    if (rc) { (void)hipStreamSynchronize(c->stream); c->pend.active = false; c->pend.launched = false; }
     return rc;
 }
 
@@ -1028,9 +1145,7 @@ int eincm_loss_grad_wait(eincm_ctx* c, double* value, double* grad, eincm_aux* a
     if (!c) return EINCM_ERR_ARG;
     if (!c->pend.active || !c->pend.launched) return fail(c, EINCM_ERR_STATE, "eincm_loss_grad_wait without eincm_loss_grad_async");
     HIPCHK(c, hipSetDevice(c->device));
-    const int rc = eval_end_collect(c, value, grad, aux);
-    if (rc && rc != EINCM_ERR_NONFINITE) { c->pend.active = false; c->pend.launched = false; }
-    return rc;
+    return eval_end_collect(c, value, grad, aux);      // drains the stream and clears the pending state on every path
 }
 
 int eincm_loss_grad(eincm_ctx* c, const double* theta, int h, int w, const eincm_params* p, double* value, double* grad, eincm_aux* aux) {
@@ -1130,10 +1245,27 @@ int eincm_get_zero_iwe(eincm_ctx* c, float* z) {
 }
 int eincm_get_image_grad(eincm_ctx* c, float* G) {
     if (c && !c->have_eval) return fail(c, EINCM_ERR_STATE, "no evaluation yet");
+    if (c && !c->G_valid) return fail(c, EINCM_ERR_STATE, "no dL/dIWE image: the last evaluation had no gradient, or eincm_get_count_images reused the buffer");
     return copy_out(c, G, c ? c->d_G : nullptr, c ? (size_t)c->g.B * c->g.R * c->g.H * c->g.W * sizeof(float) : 0);
 }
+// 2-DoF evaluations skip the Theta image; build it when somebody asks for it
+static int ensure_theta_image(eincm_ctx* c) {
+    if (c->Theta_valid) return EINCM_OK;
+    if (c->last_theta11.size() != (size_t)c->g.B * 2) return fail(c, EINCM_ERR_STATE, "no evaluation yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = ensure_resample(c, 1, 1, EINCM_METHOD_BILINEAR);      // a (1,1,2) theta upsamples to a constant with every method
+    if (rc) return rc;
+    memcpy(c->h_theta, c->last_theta11.data(), c->last_theta11.size() * sizeof(double));
+    ThetaArg targ{};
+    launch_theta_image(c, 1, 1, false, false, targ, c->h_theta);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EINCM_OK;
+}
+
 int eincm_get_scaled_theta(eincm_ctx* c, double* T) {
     if (c && !c->have_eval) return fail(c, EINCM_ERR_STATE, "no evaluation yet");
+    if (c && c->staged) { const int rc = ensure_theta_image(c); if (rc) return rc; }
     return copy_out(c, T, c ? c->d_Theta : nullptr, c ? (size_t)c->g.B * c->g.H * c->g.W * 2 * sizeof(double) : 0);
 }
 
@@ -1142,10 +1274,12 @@ int eincm_get_count_images(eincm_ctx* c, uint32_t* counts) {
     if (!counts) return fail(c, EINCM_ERR_ARG, "null pointer argument");
     if (!c->staged || !c->have_eval) return fail(c, EINCM_ERR_STATE, "no evaluation yet");
     HIPCHK(c, hipSetDevice(c->device));
+    { const int rc = ensure_theta_image(c); if (rc) return rc; }
     const Geom& g = c->g;
     const size_t n = (size_t)g.B * g.R * g.H * g.W;
     // the dL/dIWE buffer is free between evaluations and has exactly this many 4-byte cells
     uint32_t* d = reinterpret_cast<uint32_t*>(c->d_G);
+    c->G_valid = false;
     HIPCHK(c, hipMemsetAsync(d, 0, n * sizeof(uint32_t), c->stream));
     if (c->n_items > 0)
         hipLaunchKernelGGL(k_count, dim3(event_grid(c)), dim3(NT), 0, c->stream, g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta,

@@ -7,9 +7,10 @@
 //   k_bin_tilescan one workgroup: exclusive scans of tile counts and of segment counts    -> tilebase, itembase, n_items
 //   k_bin_scatter  per block: position = tilebase + blockoff + LDS rank                   -> ev_xy, ev_t (binned)
 //   k_items / k_seg_minmax                                                                -> segments with their time range
-// Blocks are taken in input order, so a tile's events stay time-ordered at 4096-event granularity (inside a block the
-// order is whatever the LDS atomics return).  Order only affects how tight a segment's time range — and hence its LDS
-// window — is; results do not depend on it beyond fp32 summation order.
+// The sort is STABLE: a block is one wave walking its 1024 events in input order, and events of a wave-step that share a tile are
+// ranked by lane (k_bin_scatter), so a tile's events keep the order they were handed over in, and staging the same window twice
+// gives the same binned arrays bit for bit.  The fp64 per-thread sums of k_gather (2-DoF theta) depend on that order, so this is
+// what makes a re-staged window reproduce its gradient exactly.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,21 +19,22 @@
 
 namespace eincm {
 
-constexpr int BIN_CHUNK = 4096;
+constexpr int BIN_CHUNK = 1024;          // events per staging block
+constexpr int BIN_NT = 64;               // one wave per block: its LDS traffic is ordered, which the stable ranking relies on
 constexpr int BIN_MAX_TILES = 12288;     // LDS histogram capacity (48 KiB); larger sensors use the host path
 
 struct BinBlock { int32_t win, start, count, first_blk; };    // start: global index of the block's first event
 
 // err[0] = smallest global index of an event outside the sensor (INT_MAX if none); err[1] = same for non-finite t
-__global__ __launch_bounds__(NT) void k_bin_hist(Geom g, const BinBlock* __restrict__ blks, const int16_t* __restrict__ xs,
+__global__ __launch_bounds__(BIN_NT) void k_bin_hist(Geom g, const BinBlock* __restrict__ blks, const int16_t* __restrict__ xs,
                                                   const int16_t* __restrict__ ys, const double* __restrict__ ts,
                                                   uint32_t* __restrict__ blockhist, int* __restrict__ err)
 {
     extern __shared__ uint32_t hist[];
     const BinBlock bb = blks[blockIdx.x];
-    for (int i = threadIdx.x; i < g.ntiles; i += NT) hist[i] = 0u;
+    for (int i = threadIdx.x; i < g.ntiles; i += BIN_NT) hist[i] = 0u;
     __syncthreads();
-    for (int i = threadIdx.x; i < bb.count; i += NT) {
+    for (int i = threadIdx.x; i < bb.count; i += BIN_NT) {
         const int e = bb.start + i;
         const int x = xs[e], y = ys[e];
         const double t = ts[e];
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(NT) void k_bin_hist(Geom g, const BinBlock* __restr
     }
     __syncthreads();
     uint32_t* out = blockhist + (size_t)blockIdx.x * g.ntiles;
-    for (int i = threadIdx.x; i < g.ntiles; i += NT) out[i] = hist[i];
+    for (int i = threadIdx.x; i < g.ntiles; i += BIN_NT) out[i] = hist[i];
 }
 
 // thread per (window, tile); win_blk (B+1): first block of each window
@@ -90,28 +92,47 @@ __global__ __launch_bounds__(1024) void k_bin_tilescan(int M, int seg, const int
     if (t == 1023) { totals[0] = (int32_t)sA[1023]; totals[1] = (int32_t)sB[1023]; }
 }
 
-__global__ __launch_bounds__(NT) void k_bin_scatter(Geom g, const BinBlock* __restrict__ blks, const int16_t* __restrict__ xs,
-                                                     const int16_t* __restrict__ ys, const double* __restrict__ ts,
-                                                     const uint32_t* __restrict__ blockoff, const int32_t* __restrict__ tilebase,
-                                                     uint32_t* __restrict__ ev_xy, double* __restrict__ ev_t)
+__global__ __launch_bounds__(BIN_NT) void k_bin_scatter(Geom g, const BinBlock* __restrict__ blks, const int16_t* __restrict__ xs,
+                                                         const int16_t* __restrict__ ys, const double* __restrict__ ts,
+                                                         const uint32_t* __restrict__ blockoff, const int32_t* __restrict__ tilebase,
+                                                         uint32_t* __restrict__ ev_xy, double* __restrict__ ev_t)
 {
-    extern __shared__ uint32_t cnt[];
+    extern __shared__ uint32_t cnt[];            // events of each tile this block has placed so far
     const BinBlock bb = blks[blockIdx.x];
-    for (int i = threadIdx.x; i < g.ntiles; i += NT) cnt[i] = 0u;
-    __syncthreads();
+    const int lane = threadIdx.x;
+    for (int i = lane; i < g.ntiles; i += BIN_NT) cnt[i] = 0u;
+    __builtin_amdgcn_wave_barrier();
     const uint32_t* off = blockoff + (size_t)blockIdx.x * g.ntiles;
     const int32_t* tb = tilebase + (size_t)bb.win * g.ntiles;
-    for (int i = threadIdx.x; i < bb.count; i += NT) {
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int i0 = 0; i0 < bb.count; i0 += BIN_NT) {          // wave-uniform trip count
+        const int i = i0 + lane;
         const int e = bb.start + i;
-        const int x = xs[e], y = ys[e];
-        if (x < 0 || x >= g.W || y < 0 || y >= g.H) continue;      // already reported by k_bin_hist
-        const double t = ts[e];
-        if (!(t - t == 0.0)) continue;
-        const int tile = (y / TS) * g.tilesX + (x / TS);
-        const uint32_t r = atomicAdd(&cnt[tile], 1u);
-        const size_t pos = (size_t)tb[tile] + off[tile] + r;
-        ev_xy[pos] = (uint32_t)(uint16_t)x | ((uint32_t)(uint16_t)y << 16);
-        ev_t[pos] = t;
+        int x = 0, y = 0; double t = 0.0; int tile = -1;
+        if (i < bb.count) {
+            x = xs[e]; y = ys[e]; t = ts[e];
+            // events outside the sensor / with a non-finite time were reported by k_bin_hist and are not placed
+            if (x >= 0 && x < g.W && y >= 0 && y < g.H && (t - t == 0.0)) tile = (y / TS) * g.tilesX + (x / TS);
+        }
+        // stable rank: lanes that share a tile are ordered by lane (= input order); the tile's running count advances once per group
+        unsigned long long todo = __ballot(tile >= 0);
+        uint32_t slot = 0u;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int T = __shfl(tile, leader, 64);
+            const unsigned long long grp = __ballot(tile == T);
+            const uint32_t base = cnt[T];                        // every lane reads the same word before the leader updates it
+            if (tile == T) slot = base + (uint32_t)__popcll(grp & lt_mask);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == leader) cnt[T] = base + (uint32_t)__popcll(grp);
+            __builtin_amdgcn_wave_barrier();
+            todo &= ~grp;
+        }
+        if (tile >= 0) {
+            const size_t pos = (size_t)tb[tile] + off[tile] + slot;
+            ev_xy[pos] = (uint32_t)(uint16_t)x | ((uint32_t)(uint16_t)y << 16);
+            ev_t[pos] = t;
+        }
     }
 }
 
@@ -151,8 +172,9 @@ __global__ __launch_bounds__(NT) void k_seg_minmax(int n_items, Item* __restrict
     }
 }
 
-// edges (B,R,H,W) double -> float, and the fp64 moments of the STORED values: sum E, sum E^2 per (b, r).
-// grid (nblk, R, B); moments (B,R,2) zeroed beforehand.
+// edges (B,R,H,W) double -> float, and the fp64 moments of the STORED values: sum E, sum E^2 per (b, r), as one partial pair
+// per block (the host adds the EDGE_PARTS pairs in index order: no atomics, bit-reproducible).  grid (EDGE_PARTS, R, B).
+constexpr int EDGE_PARTS = 32;
 __global__ __launch_bounds__(NT) void k_edges(Geom g, const double* __restrict__ src, float* __restrict__ dst, double* __restrict__ moments)
 {
     __shared__ double scratch[NWAVE];
@@ -166,7 +188,34 @@ __global__ __launch_bounds__(NT) void k_edges(Geom g, const double* __restrict__
     }
     s = block_sum(s, scratch);
     ss = block_sum(ss, scratch);
-    if (threadIdx.x == 0) { atomicAdd(moments + ((size_t)b * g.R + r) * 2, s); atomicAdd(moments + ((size_t)b * g.R + r) * 2 + 1, ss); }
+    if (threadIdx.x == 0) {
+        double* o = moments + (((size_t)b * g.R + r) * EDGE_PARTS + blockIdx.x) * 2;
+        o[0] = s; o[1] = ss;
+    }
+}
+
+// Per window: first segment index (segments are ordered by window) and dtmax = max |t - tau_r| over its events and reference
+// times, from the segments' exact time ranges.  grid (B), one workgroup each.  itembase: (B*ntiles) first segment of each tile.
+__global__ __launch_bounds__(NT) void k_win_consts(Geom g, int n_items, const Item* __restrict__ items, const int32_t* __restrict__ itembase,
+                                                    const double* __restrict__ edge_ts, int32_t* __restrict__ win_item0,
+                                                    double* __restrict__ dtmax)
+{
+    __shared__ double smn[NWAVE], smx[NWAVE];
+    const int b = blockIdx.x;
+    const int lo = itembase[(size_t)b * g.ntiles], hi = (b + 1 < g.B) ? itembase[(size_t)(b + 1) * g.ntiles] : n_items;
+    double mn = INFINITY, mx = -INFINITY;
+    for (int k = lo + threadIdx.x; k < hi; k += NT) { mn = fmin(mn, items[k].t_lo); mx = fmax(mx, items[k].t_hi); }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < NWAVE; ++i) { mn = fmin(mn, smn[i]); mx = fmax(mx, smx[i]); }
+        double d = 0.0;
+        if (hi > lo)
+            for (int r = 0; r < g.R; ++r) { const double tau = edge_ts[b * g.R + r]; d = fmax(d, fmax(fabs(mn - tau), fabs(mx - tau))); }
+        win_item0[b] = lo;
+        dtmax[b] = d;
+    }
 }
 
 }  // namespace eincm

@@ -13,8 +13,14 @@
 //   k_final   scalar assembly of the loss, aux and the final gradient               [losses.py:176-203]
 // Events are binned once per window by 32x32 SOURCE tile (time order kept inside a tile) and cut into
 // work items of <= chunk events; because Theta is smooth and an item spans a known time range, the
-// destinations of an item fall in a small bounding box that lives in LDS (fp32 ds_add), so HBM sees one
+// destinations of an item fall in a small bounding box that lives in LDS (u32 fixed-point ds_add), so HBM sees one
 // coalesced row-wise flush per item instead of 9 scattered atomics per warped event.
+//
+// Every accumulation that crosses workgroups is INTEGER (fixed point): the IWE stack is summed as u32 at a per-window scale
+// (k_splat -> acc, converted to the fp32 IWE by the statistics pass), dL/dTheta and dL/dtheta as i64 at a per-window scale derived
+// from max|dL/dIWE| (k_gather / k_project), and the 2-DoF gradient as per-workgroup fp64 partials summed in a fixed order
+// (k_final).  Integer adds commute, so results are bit-identical from run to run whatever order the hardware retires atomics in.
+// Accumulators are cleared by their CONSUMER (read, then write 0), never by a separate clear pass.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -79,7 +85,40 @@ struct WinConst {                 // theta-independent constants of a window (lo
     double zc[16];                // zero_corrs[r] = -MSE(E_r, n0)
     double sE[16], sEE[16];       // sum E_r, sum E_r^2
     double mrw[16];               // multi-reference weights (losses.py:39-46)
+    double dtmax;                 // max |t_e - tau_r| over the window's events and reference times (bounds a gradient term)
+    double nev;                   // events that may contribute to this window's images (all shards of an event-sharded window)
+    int32_t gshift, _pad;         // the u32 IWE accumulator of this window holds pixel * 2^gshift (iwe_shift)
 };
+
+// Scale of a window's u32 IWE accumulator.  One tap is <= 1/(2 pi) and no event puts two taps on one pixel, so a pixel is at most
+// 0.1592 * nev whatever theta is: 2^k with 0.16 * nev * 2^k <= 2^32 cannot overflow (a window of 10^6 events: k = 14, of 3*10^4: k = 19).
+__host__ __device__ __forceinline__ int iwe_shift(double nev) {
+    int k = 30;
+    while (k > 0 && 0.16 * nev * (double)(1u << k) > 4294967295.0) --k;
+    return k;
+}
+
+// i64 fixed point of the gradient accumulators: value * 2^eg, magnitudes < 2^51 so that (a) the fp64 -> i64 conversion by the
+// 1.5 * 2^52 magic constant is exact rounding and (b) i64 -> fp64 is exact.  bound = an upper bound of the sum of the magnitudes of
+// everything that can be added into one accumulator; returns eg with bound * 2^eg < 2^50.
+__device__ __forceinline__ int fix64_shift(double bound) {
+    if (!(bound > 0.0) || !(bound < 1.0e300)) return 0;          // nothing to add, or NaN / Inf (the loss is NaN then anyway)
+    int e;
+    (void)frexp(bound, &e);                                      // bound < 2^e
+    return 50 - e;
+}
+constexpr double FIX64_MAGIC = 6755399441055744.0;               // 1.5 * 2^52: low 32 bits of its pattern are zero
+__device__ __forceinline__ long long fix64(double scaled) {      // round-to-nearest-even integer of |scaled| < 2^51
+    return __double_as_longlong(scaled + FIX64_MAGIC) - __double_as_longlong(FIX64_MAGIC);
+}
+// |dL/dw| of one event at one reference time is at most max|G| * sum_taps k |q| <= max|G| * 9 * 0.1592 * 1.5 = 2.15 max|G|; times
+// |dt| <= dtmax; summed over nev * R events; times <= 4 for the resampling weights of the projection (sum |A_H||A_W| of any method).
+__device__ __forceinline__ int grad_shift(const WinConst& c, const unsigned* __restrict__ gmax_row, int R) {
+    unsigned m = 0u;
+    for (int r = 0; r < R; ++r) m = max(m, gmax_row[r]);         // non-negative floats order like their bit patterns
+    const double gm = (double)__uint_as_float(m);
+    return fix64_shift(2.15 * gm * c.dtmax * fmax(c.nev, 1.0) * (double)R * 4.0);
+}
 
 struct EvalParams {
     double alpha, beta, gamma, delta;
@@ -87,12 +126,6 @@ struct EvalParams {
     int want_div, want_tv, use_tv_grad;
     int h, w, identity;
 };
-
-// 2-DoF theta: every k_gather workgroup adds its share of dL/dtheta to global memory.  One address pair would serialise
-// those fp64 atomics at a single L2 channel (~14 ns per workgroup: k_gather took 133 us instead of 35 with 8x more, shorter
-// segments), so they are spread over NSLOT11 slots 256 B apart inside the window's coarse accumulator; k_final sums the slots.
-constexpr int NSLOT11 = 64;
-constexpr int SLOT11_STRIDE = 32;     // doubles
 
 constexpr int THETA_ARG_MAX = 128;    // doubles of theta that ride in the kernel arguments instead of an H2D copy
 struct ThetaArg { double v[THETA_ARG_MAX]; };
@@ -222,12 +255,10 @@ __device__ __forceinline__ uint32_t fix_u32(float a, float b) { return (uint32_t
 
 // ------------------------------------------------------------------------------------------------
 // k_theta: Theta = A_H theta A_W^T per channel, and per-tile velocity bounds.
-// grid (ntiles, B).  identity: theta already is (H,W,2).
+// grid (ntiles, B).  identity: theta already is (H,W,2).  Not launched for 2-DoF theta unless somebody needs the Theta image
+// (k_theta_const fills the velocity bounds then).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity, int use_arg, ThetaArg targ,
-        float* __restrict__ iwe,               // (B,R,H,W)  cleared here (one launch instead of three memsets)
-        float* __restrict__ gTheta,            // (B,H,W,2)  cleared here, or nullptr (forward only)
-        double* __restrict__ gth, size_t gth_half_stride, int gth_cap,   // coarse accumulators (2 halves, B, gth_cap) or nullptr
         const double* __restrict__ theta,      // (B,h,w,2)
         const double* __restrict__ AH,         // (H,h)
         const double* __restrict__ AW,         // (W,w)
@@ -242,25 +273,6 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const double* th = theta + (size_t)b * h * w * 2;
     double* Th = Theta + (size_t)b * g.H * g.W * 2;
-    // fused clears: the IWE stack and dL/dTheta are cleared as flat arrays, each block taking one contiguous slice with
-    // 16-byte stores (tile-shaped clears were scalar and strided: 20 stores per thread); block 0 of each window clears its
-    // coarse accumulators
-    {
-        const size_t nblk = (size_t)gridDim.x * gridDim.y, blk = (size_t)b * gridDim.x + tile;
-        auto clear_flat = [&](float* __restrict__ base, size_t n) {
-            const size_t n4 = n >> 2, per = (n4 + nblk - 1) / nblk;
-            const size_t lo = blk * per, hi = (lo + per < n4) ? lo + per : n4;
-            float4* __restrict__ q = reinterpret_cast<float4*>(base);
-            for (size_t i = lo + threadIdx.x; i < hi; i += NT) q[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (blk == 0 && threadIdx.x < (n & 3)) base[(n4 << 2) + threadIdx.x] = 0.0f;
-        };
-        clear_flat(iwe, (size_t)g.B * g.R * g.H * g.W);
-        if (gTheta) clear_flat(gTheta, (size_t)g.B * g.H * g.W * 2);
-    }
-    if (gth && tile == 0) {
-        const int n = min(h * w == 1 ? NSLOT11 * SLOT11_STRIDE : h * w * 2, gth_cap);
-        for (int i = threadIdx.x; i < n; i += NT) { gth[(size_t)b * gth_cap + i] = 0.0; gth[gth_half_stride + (size_t)b * gth_cap + i] = 0.0; }
-    }
     double mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
     bool nan = false;
     for (int p = threadIdx.x; p < TS * TS; p += NT) {
@@ -320,6 +332,19 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
     }
 }
 
+// 2-DoF theta (1,1,2): Theta is one constant per window, so the velocity bounds of every tile are that constant; no image is
+// written.  grid (ceil(B*ntiles/NT)).  theta rides in the kernel arguments (B*2 <= THETA_ARG_MAX) or is read from `theta`.
+__global__ __launch_bounds__(NT) void k_theta_const(Geom g, int use_arg, ThetaArg targ, const double* __restrict__ theta,
+                                                     double* __restrict__ tmm)
+{
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= g.B * g.ntiles) return;
+    const int b = i / g.ntiles;
+    const double vx = use_arg ? targ.v[2 * b] : theta[2 * b], vy = use_arg ? targ.v[2 * b + 1] : theta[2 * b + 1];
+    double* o = tmm + (size_t)i * 4;
+    o[0] = vx; o[1] = vx; o[2] = vy; o[3] = vy;          // NaN stays NaN: item_window and k_final see it
+}
+
 // Block -> (segment, reference time).  The R blocks that process one segment at the R reference times read the
 // same events; blocks b, b+8, b+16, ... are dealt to the same XCD back to back, so they are made siblings and
 // the 2nd..Rth read of a segment's events hits that XCD's L2 instead of HBM.  grid = ceil(n_items/8)*8*R.
@@ -344,7 +369,8 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
         const double* __restrict__ Theta,      // (B,H,W,2)
         const double* __restrict__ tmm,        // (B,ntiles,4)
         const double* __restrict__ edge_ts,    // (B,R)
-        float* __restrict__ iwe)               // (B,R,H,W), zeroed
+        const WinConst* __restrict__ wc,       // (B): the window's accumulator scale
+        uint32_t* __restrict__ acc)            // (B,R,H,W) u32 fixed point at 2^gshift, zero on entry (cleared by its consumer)
 {
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsu[];
@@ -377,7 +403,9 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     }
     __syncthreads();
 
-    float* __restrict__ img = iwe + ((size_t)it.win * g.R + r) * g.H * g.W;
+    uint32_t* __restrict__ img = acc + ((size_t)it.win * g.R + r) * g.H * g.W;
+    const int gshift = wc[it.win].gshift;
+    const float GSCALE = ldexpf(1.0f, gshift);
     const uint32_t* __restrict__ exy = ev_xy + it.begin;
     const double* __restrict__ et = ev_t + it.begin;
     const int n = it.count;
@@ -427,7 +455,8 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
                         atomicAdd(ldsu + cy * wn.ww + cx, fix_u32(ky[dy], kx[dx]));
                     } else {
                         const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
-                        if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, ky[dy] * kx[dx] * FIX_INV);
+                        // straight to HBM in the accumulator's own scale (ky carries 2^fshift)
+                        if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, fix_u32(ky[dy] * FIX_INV * GSCALE, kx[dx]));
                     }
                 }
             }
@@ -460,15 +489,23 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
         if (j + 2 < iters) step(C, A, B, j + 2);
     }
     if (!multi) __syncthreads();
-    // row-wise flush: a wave walks one window row -> contiguous fp32 atomics on one image row
+    // row-wise flush: a wave walks one window row -> contiguous u32 atomics on one image row.  The segment's exact integer sums
+    // (scale 2^fshift) are rounded once to the window's accumulator scale 2^gshift; integer adds commute, so the image does not
+    // depend on the order in which the workgroups arrive.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int down = fshift - gshift;                // > 0: drop bits (round to nearest), <= 0: exact left shift
+    auto to_acc = [&](int i) -> uint32_t {
+        if (multi) return (uint32_t)fmaf(ldsf[i], GSCALE, 0.5f);
+        const uint32_t u = ldsu[i];
+        return down > 0 ? ((u >> down) + ((u >> (down - 1)) & 1u)) : (u << (-down));     // round half up without a carry out of 32 bits
+    };
     if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {
         // the usual case, the window lies inside the image: no index rule per pixel
-        float* __restrict__ dst = img + (size_t)wn.oy * g.W + wn.ox;
+        uint32_t* __restrict__ dst = img + (size_t)wn.oy * g.W + wn.ox;
         for (int row = wv; row < wn.wh; row += NWAVE) {
             for (int col = lane; col < wn.ww; col += 64) {
-                const float v = multi ? ldsf[row * wn.ww + col] : (float)ldsu[row * wn.ww + col] * FIX_INV;
-                if (v != 0.0f) atomicAdd(dst + row * g.W + col, v);
+                const uint32_t v = to_acc(row * wn.ww + col);
+                if (v != 0u) atomicAdd(dst + row * g.W + col, v);
             }
         }
         return;
@@ -477,8 +514,8 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
         const int gy = wrap_drop(wn.oy + row, g.H);
         if (gy < 0) continue;
         for (int col = lane; col < wn.ww; col += 64) {
-            const float v = multi ? ldsf[row * wn.ww + col] : (float)ldsu[row * wn.ww + col] * FIX_INV;
-            if (v != 0.0f) {
+            const uint32_t v = to_acc(row * wn.ww + col);
+            if (v != 0u) {
                 const int gx = wrap_drop(wn.ox + col, g.W);
                 if (gx >= 0) atomicAdd(img + (size_t)gy * g.W + gx, v);
             }
@@ -569,18 +606,39 @@ __global__ __launch_bounds__(NT) void k_stats(Geom g, const float* __restrict__ 
     }
 }
 
+// k_iwe_finish: the u32 accumulator becomes the fp32 IWE stack, and is cleared for the next evaluation (consumer-clears).
+// Used on the paths whose statistics kernel is the tiled k_stats (forward-only evaluations); gradient evaluations do the same
+// inside k_stats_stream.  grid-stride over (B,R,H,W); also resets the max|dL/dIWE| words.
+__global__ __launch_bounds__(NT) void k_iwe_finish(Geom g, uint32_t* __restrict__ acc, float* __restrict__ iwe,
+                                                    const WinConst* __restrict__ wc, unsigned* __restrict__ gmax)
+{
+    const size_t per = (size_t)g.R * g.H * g.W, n = per * g.B;
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < g.B * g.R; k += NT) gmax[k] = 0u;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        const uint32_t a = acc[i];
+        iwe[i] = ldexpf((float)a, -wc[i / per].gshift);
+        if (a != 0u) acc[i] = 0u;
+    }
+}
+
 // k_stats_stream: the same partials as k_stats without the contrast energy, as a pure streaming reduction.  The partials have
 // no per-tile meaning (they are only ever reduced over the whole image), so NSPART fat blocks per image read the image with
 // coalesced grid-stride loads and pay the fp64 cross-lane reduction once each.  grid (NSPART, R, B).
+// It is also the consumer of the u32 accumulator: converts it to the fp32 IWE stack (what every later kernel reads) and clears it.
 constexpr int NSPART = 32;
-__global__ __launch_bounds__(NT) void k_stats_stream(Geom g, const float* __restrict__ iwe, const float* __restrict__ edges,
-                                                      StatPart* __restrict__ parts)
+__global__ __launch_bounds__(NT) void k_stats_stream(Geom g, uint32_t* __restrict__ acc, float* __restrict__ iwe,
+                                                      const float* __restrict__ edges, const WinConst* __restrict__ wc,
+                                                      StatPart* __restrict__ parts, unsigned* __restrict__ gmax)
 {
     __shared__ double red[NWAVE][8];
     const int part = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
     const size_t n = (size_t)g.H * g.W;
-    const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * n;
+    uint32_t* __restrict__ A = acc + ((size_t)b * g.R + r) * n;
+    float* __restrict__ I = iwe + ((size_t)b * g.R + r) * n;
     const float* __restrict__ E = edges + ((size_t)b * g.R + r) * n;
+    const float inv = ldexpf(1.0f, -wc[b].gshift);
+    if (part == 0 && threadIdx.x == 0) gmax[b * g.R + r] = 0u;       // k_imgrad raises it again (atomicMax)
     double mn = INFINITY, mx = -INFINITY, cmn = 0.0, cmx = 0.0, sI = 0.0, sII = 0.0, sEI = 0.0;
     auto take = [&](float fv, float fe) {          // branch-free: (min, #ties) and (max, #ties) are tracked with selects
         const double v = (double)fv, e = (double)fe;
@@ -589,15 +647,21 @@ __global__ __launch_bounds__(NT) void k_stats_stream(Geom g, const float* __rest
         mn = fmin(mn, v); mx = fmax(mx, v);
         sI += v; sII += v * v; sEI += e * v;
     };
+    auto conv = [&](int i, uint32_t a) -> float {  // u32 -> fp32 pixel (rounds to 24 bits), stored for the later kernels; clear
+        const float v = (float)a * inv;
+        I[i] = v;
+        if (a != 0u) A[i] = 0u;
+        return v;
+    };
     // four independent load pairs in flight per trip: with one pair per trip the loop paid a full memory latency 11 times
     const int npx = (int)n, stride = NSPART * NT;
     int i = part * NT + (int)threadIdx.x;
     for (; i + 3 * stride < npx; i += 4 * stride) {
-        const float v0 = I[i], v1 = I[i + stride], v2 = I[i + 2 * stride], v3 = I[i + 3 * stride];
+        const uint32_t a0 = A[i], a1 = A[i + stride], a2 = A[i + 2 * stride], a3 = A[i + 3 * stride];
         const float e0 = E[i], e1 = E[i + stride], e2 = E[i + 2 * stride], e3 = E[i + 3 * stride];
-        take(v0, e0); take(v1, e1); take(v2, e2); take(v3, e3);
+        take(conv(i, a0), e0); take(conv(i + stride, a1), e1); take(conv(i + 2 * stride, a2), e2); take(conv(i + 3 * stride, a3), e3);
     }
-    for (; i < npx; i += stride) take(I[i], E[i]);
+    for (; i < npx; i += stride) take(conv(i, A[i]), E[i]);
     const double wmn = wave_min(mn), wmx = wave_max(mx);
     const double bmn = __shfl(wmn, 0, 64), bmx = __shfl(wmx, 0, 64);
     cmn = wave_sum(mn == bmn ? cmn : 0.0);
@@ -656,9 +720,12 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
         const StatPart* __restrict__ parts, const WinConst* __restrict__ wc,
         const float* __restrict__ gdiv, const double* __restrict__ dgparts,    // delta != 0 only (else unused)
         double* __restrict__ g2parts,          // (B,R,ntiles): this tile's sum of gx^2+gy^2 (contrast energy), a by-product
-        float* __restrict__ G)
+        float* __restrict__ G,
+        unsigned* __restrict__ gmax)           // (B,R): max |G| as float bits (atomicMax; zeroed by the statistics pass): fixes the
+                                               // fixed-point scale of the gradient accumulators (grad_shift)
 {
     __shared__ double g2scratch[NWAVE];
+    __shared__ float gmscratch[NWAVE];
     constexpr int P2 = TS + 4, P1 = TS + 2;
     __shared__ float t[P2][P2 + 1];
     __shared__ float sgx[P1][P1 + 1], sgy[P1][P1 + 1];   // fp32 stencils: inputs (IWE) and output (G) are fp32 images
@@ -729,6 +796,7 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
     g2 = block_sum(g2, g2scratch);
     if (threadIdx.x == 0) g2parts[((size_t)b * g.R + r) * g.ntiles + tile] = g2;
     const double m = sc[0], M = sc[1], D = sc[2];
+    float gm = 0.0f;
     for (int p = threadIdx.x; p < TS * TS; p += NT) {
         const int ly = p / TS, lx = p % TS;
         const int y = y0 + ly, x = x0 + lx;
@@ -752,7 +820,18 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
         if (use_div) gv += sc[8] * (double)gdiv[((size_t)b * g.R + r) * g.H * g.W + (size_t)y * g.W + x];
         if (v == m) gv += sc[5];
         if (v == M) gv += sc[6];
-        Go[(size_t)y * g.W + x] = (float)gv;
+        const float gf = (float)gv;
+        Go[(size_t)y * g.W + x] = gf;
+        gm = (gf == gf) ? fmaxf(gm, fabsf(gf)) : INFINITY;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_down(gm, o, 64));
+    if ((threadIdx.x & 63) == 0) gmscratch[threadIdx.x >> 6] = gm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < NWAVE; ++i) gm = fmaxf(gm, gmscratch[i]);
+        // max is order-independent: the value every later kernel reads does not depend on who arrives first
+        if (gm > 0.0f) atomicMax(gmax + b * g.R + r, __float_as_uint(gm));
     }
 }
 
@@ -903,16 +982,19 @@ __global__ __launch_bounds__(NT) void k_divgrad(Geom g, const float* __restrict_
 // k_gather: reverse of the splat.  grid as k_splat (block_to_work).  For every event of the segment and this reference time:
 //   dL/dwx = sum_taps G[p] * k * qx,  dL/dwy likewise (q = p - w; dropped taps contribute 0, wrapped taps read
 //   the wrapped pixel), then dL/dTheta[y,x,:] += -dt * (dL/dwx, dL/dwy)   (event_warpers.py:34-35).
-// The G window is staged in LDS with the same bounding box as the forward; per-pixel sums are accumulated in an
-// LDS copy of the source tile and flushed row-wise.
+// The G window is staged in LDS with the same bounding box as the forward.  2-DoF theta (direct11): every thread sums its events in
+// fp64 in a fixed order, the workgroup reduces them in a fixed order and STORES its partial in its own slot (k_final adds the
+// slots in index order).  Otherwise: per-pixel sums are accumulated in an LDS copy of the source tile as i64 fixed point
+// (ds_add_u64; scale grad_shift) and flushed with i64 global atomics.  Both are bit-reproducible.
 // ------------------------------------------------------------------------------------------------
 template <int TM>      // TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
 __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
         const double* __restrict__ Theta, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
         const float* __restrict__ G,           // (B,R,H,W)
-        float* __restrict__ gTheta,            // (B,H,W,2), zeroed
-        int direct11, double* __restrict__ gth_main, int gth_cap,   // 2-DoF theta: sum straight into dL/dtheta (B,gth_cap)
+        long long* __restrict__ gTheta,        // (B,H,W,2) i64 fixed point, zero on entry (cleared by its consumer)
+        int direct11, double* __restrict__ g11,                     // 2-DoF theta: (n_items, R, 2) per-workgroup partials of dL/dtheta
+        const WinConst* __restrict__ wc, const unsigned* __restrict__ gmax,   // scale of the i64 accumulators (grad_shift)
         int theta_mode)
 {
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
@@ -920,7 +1002,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     // LDS: [G window: wincap floats][accum: TS*TS*2 doubles unless direct11][Theta tile: TS*TS double2 if THETA_TILE]
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red11[NWAVE];
-    double* accum = reinterpret_cast<double*>(lds + g.wincap);   // ds_add_f64 is ~10x ds_add_f32 on gfx950
+    unsigned long long* accum = reinterpret_cast<unsigned long long*>(lds + g.wincap);   // i64 fixed point: ds_add_u64 (3.7 lane-ops/clk/CU; ds_add_f32: 0.33)
     double2* thtile = reinterpret_cast<double2*>(lds + g.wincap + (direct11 ? 0 : TS * TS * 4));
     double sum11x = 0.0, sum11y = 0.0;          // direct11: this thread's share of sum_e -dt * dL/dw
     int item, r;
@@ -943,8 +1025,11 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
             }
         }
     }
-    if (!direct11)
-        for (int i = threadIdx.x; i < TS * TS * 2; i += NT) accum[i] = 0.0;
+    double gscale = 0.0;                          // 2^eg of this window's gradient accumulators
+    if (!direct11) {
+        for (int i = threadIdx.x; i < TS * TS * 2; i += NT) accum[i] = 0ull;
+        gscale = ldexp(1.0, grad_shift(wc[it.win], gmax + it.win * g.R, g.R));
+    }
     const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
     double2 vconst = make_double2(0.0, 0.0);
@@ -1018,9 +1103,10 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         if (direct11) {          // theta (1,1,2): Theta is constant, dL/dtheta = sum over all events; no per-pixel image needed
             sum11x -= dt * (double)gwx; sum11y -= dt * (double)gwy;
         } else {
-            double* a = accum + ((((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)) << 1);
-            atomicAdd(a, -dt * (double)gwx);
-            atomicAdd(a + 1, -dt * (double)gwy);
+            unsigned long long* a = accum + ((((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)) << 1);
+            const double sdt = -dt * gscale;
+            atomicAdd(a, (unsigned long long)fix64(sdt * (double)gwx));
+            atomicAdd(a + 1, (unsigned long long)fix64(sdt * (double)gwy));
         }
     };
     // a plain strided loop: with 8 waves per SIMD the loads are hidden by occupancy; the renamed-register pipeline of
@@ -1033,20 +1119,183 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     if (direct11) {
         sum11x = block_sum(sum11x, red11);
         sum11y = block_sum(sum11y, red11);
-        if (threadIdx.x == 0) {
-            double* dst = gth_main + (size_t)it.win * gth_cap + (blockIdx.x & (NSLOT11 - 1)) * SLOT11_STRIDE;
-            if (sum11x != 0.0) atomicAdd(dst, sum11x);
-            if (sum11y != 0.0) atomicAdd(dst + 1, sum11y);
+        if (threadIdx.x == 0) {          // own slot, plain store, written unconditionally: nothing to clear, nothing to order
+            double* dst = g11 + ((size_t)item * g.R + r) * 2;
+            dst[0] = sum11x; dst[1] = sum11y;
         }
         return;
     }
     __syncthreads();
-    float* __restrict__ gT = gTheta + (size_t)it.win * g.H * g.W * 2;
+    unsigned long long* __restrict__ gT = reinterpret_cast<unsigned long long*>(gTheta) + (size_t)it.win * g.H * g.W * 2;
     const int tw = min(TS, g.W - x0), th = min(TS, g.H - y0);
     for (int i = threadIdx.x; i < TS * TS * 2; i += NT) {
         const int c = i & 1, px = (i >> 1) % TS, py = (i >> 1) / TS;
-        const double v = accum[i];
-        if (px < tw && py < th && v != 0.0) atomicAdd(gT + ((size_t)(y0 + py) * g.W + (x0 + px)) * 2 + c, (float)v);
+        const unsigned long long v = accum[i];
+        if (px < tw && py < th && v != 0ull) atomicAdd(gT + ((size_t)(y0 + py) * g.W + (x0 + px)) * 2 + c, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gather11: the reverse of the splat for 2-DoF theta (1,1,2), all reference times of a segment in ONE workgroup.
+// grid n_items * nrg (nrg = ceil(R / RF) groups of <= RF reference times; item = blockIdx / nrg after the XCD band mapping).
+// What is shared across the reference times is done once per event instead of R times: the event load, the unpacking, and the
+// fp64 part of the warp.  With a constant velocity v the warped coordinate is  w_r = x - v (t - tau_r) = A + c_r,  A = x - v t
+// (per event, fp64), c_r = v tau_r (per reference time, uniform).  Both are split once into integer and fraction,
+// A = Ai + Af, c_r = ci_r + cf_r, and the per-(event, r) work is fp32 / integer:  s = Af + cf_r in [-1, 1],  rs = rint(s),
+// f = s - rs,  round(w_r) = Ai + ci_r + rs.  That differs from the reference's own operation order by < 2.5e-7 px in f, which is
+// harmless for the taps (fp32 anyway) but could flip a rounding decision when w_r is within that distance of a half-integer:
+// lanes with |f| > 0.5 - 2.5e-7 (about one in 10^6) redo the warp exactly as the reference does (fp64, warp_axis), and so does
+// everything when |v| > 1e5 px / window or v is not finite (A would lose the bits the split relies on).
+// The G windows of the group's reference times sit side by side in LDS (read-only: no LDS atomics in this kernel); the thread's
+// sums are fp32 over its own <= 128 terms, then fp64 in a fixed order (block_sum), stored in the workgroup's own slot.
+// ------------------------------------------------------------------------------------------------
+constexpr int G11_RF = 5;         // reference times per workgroup: 5 x 9 KiB windows -> 3 workgroups per CU
+template <int RF>
+__global__ __launch_bounds__(NT) void k_gather11(Geom g, int n_items, int nrg, int wincap,
+        const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
+        const double* __restrict__ tmm, const double* __restrict__ edge_ts,
+        const float* __restrict__ G,           // (B,R,H,W)
+        double* __restrict__ g11)              // (n_items, nrg, 2) per-workgroup partials of dL/dtheta
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // RF windows of wincap floats
+    __shared__ double red11[NWAVE];
+    // XCD bands: blocks b, b+8, ... share an L2; give each XCD a contiguous eighth of the (window-major) work so that the G images
+    // its workgroups stage stay in that L2
+    const int nblk = n_items * nrg;
+    const int per = (nblk + NXCD - 1) / NXCD;
+    const int work = (blockIdx.x % NXCD) * per + blockIdx.x / NXCD;
+    if (work >= nblk) return;
+    const int item = work / nrg, grp = work % nrg;
+    const int r0 = grp * RF;
+    const Item it = items[item];
+    const double* mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
+    const double vx = mm[0], vy = mm[2];
+    const bool exact_only = !(fabs(vx) <= 1.0e5 && fabs(vy) <= 1.0e5);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+    // per reference time (uniform): window, integer / fractional part of c_r = v tau_r, fp32 tau
+    int wox[RF], woy[RF], www[RF], wwh[RF], cix[RF], ciy[RF];
+    float cfx[RF], cfy[RF], tauf[RF];
+    double taud[RF];
+    Geom gw = g; gw.wincap = wincap;
+#pragma unroll
+    for (int k = 0; k < RF; ++k) {
+        const int r = min(r0 + k, g.R - 1);                 // a partial last group repeats the last reference time (its sums are dropped)
+        const double tau = edge_ts[it.win * g.R + r];
+        const Window wn = item_window(gw, it, mm, tau);
+        wox[k] = wn.ox; woy[k] = wn.oy; www[k] = wn.ww; wwh[k] = wn.wh;
+        const double cx = vx * tau, cy = vy * tau;
+        const double rcx = rint(cx), rcy = rint(cy);
+        cix[k] = exact_only ? 0 : (int)rcx; ciy[k] = exact_only ? 0 : (int)rcy;
+        cfx[k] = (float)(cx - rcx); cfy[k] = (float)(cy - rcy);
+        taud[k] = tau; tauf[k] = (float)tau;
+        // stage the G window of this reference time
+        const float* __restrict__ Gi = G + ((size_t)it.win * g.R + r) * g.H * g.W;
+        float* __restrict__ win = lds + k * wincap;
+        if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {
+            const float* __restrict__ src = Gi + (size_t)wn.oy * g.W + wn.ox;
+            for (int row = wv; row < wn.wh; row += NWAVE)
+                for (int col = lane; col < wn.ww; col += 64) win[row * wn.ww + col] = src[row * g.W + col];
+        } else {
+            for (int row = wv; row < wn.wh; row += NWAVE) {
+                const int gy = wrap_drop(wn.oy + row, g.H);
+                for (int col = lane; col < wn.ww; col += 64) {
+                    const int gx = wrap_drop(wn.ox + col, g.W);
+                    win[row * wn.ww + col] = (gx >= 0 && gy >= 0) ? Gi[(size_t)gy * g.W + gx] : 0.0f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const uint32_t* __restrict__ exy = ev_xy + it.begin;
+    const double* __restrict__ et = ev_t + it.begin;
+    const int n = it.count;
+    float accx[RF], accy[RF];
+#pragma unroll
+    for (int k = 0; k < RF; ++k) { accx[k] = 0.0f; accy[k] = 0.0f; }
+    constexpr float RISK = 0.5f - 2.5e-7f;
+
+    for (int e = threadIdx.x; e < n; e += NT) {
+        const uint32_t xy = exy[e];
+        const double t = et[e];
+        const int x = xy & 0xffff, y = xy >> 16;
+        // A = x - v t, split into integer and fraction (fp64, once per event)
+        const double Ax = fma(-vx, t, (double)x), Ay = fma(-vy, t, (double)y);
+        const double Arx = rint(Ax), Ary = rint(Ay);
+        const int aix = (int)Arx, aiy = (int)Ary;
+        const float afx = (float)(Ax - Arx), afy = (float)(Ay - Ary);
+        const float tf = (float)t;
+#pragma unroll
+        for (int k = 0; k < RF; ++k) {
+            float sx = afx + cfx[k], sy = afy + cfy[k];
+            const float rsx = rintf(sx), rsy = rintf(sy);
+            float fx = sx - rsx, fy = sy - rsy;
+            int irx = aix + cix[k] + (int)rsx, iry = aiy + ciy[k] + (int)rsy;
+            if (exact_only || fmaxf(fabsf(fx), fabsf(fy)) > RISK) {       // rare: the reference's own operation order decides
+                const double dt = t - taud[k];
+                warp_axis(x, vx, dt, irx, fx);
+                warp_axis(y, vy, dt, iry, fy);
+            }
+            f2v km, k0, kp;
+            taps3x2(fx, fy, INV_2PI, km, k0, kp);
+            // weights of the x- and y-derivative: W[d] = K[d] * ((d - 1) - f)
+            const float wx0 = fmaf(-km.x, fx, -km.x), wx1 = -k0.x * fx, wx2 = fmaf(-kp.x, fx, kp.x);
+            const float wy0 = fmaf(-km.y, fy, -km.y), wy1 = -k0.y * fy, wy2 = fmaf(-kp.y, fy, kp.y);
+            const int lx = irx - 1 - wox[k], ly = iry - 1 - woy[k];
+            float g00, g01, g02, g10, g11v, g12, g20, g21, g22;
+            if ((unsigned)lx < (unsigned)(www[k] - 2) && (unsigned)ly < (unsigned)(wwh[k] - 2)) {
+                const float* p = lds + k * wincap + __mul24(ly, www[k]) + lx;
+                const float* p1 = p + www[k]; const float* p2 = p1 + www[k];
+                g00 = p[0]; g01 = p[1]; g02 = p[2];
+                g10 = p1[0]; g11v = p1[1]; g12 = p1[2];
+                g20 = p2[0]; g21 = p2[1]; g22 = p2[2];
+            } else {                                                       // taps outside the window: straight from HBM, JAX index rule
+                const int r = min(r0 + k, g.R - 1);
+                const float* __restrict__ Gi = G + ((size_t)it.win * g.R + r) * g.H * g.W;
+                const float* win = lds + k * wincap;
+                float gv[3][3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int cx = lx + dx, cy = ly + dy;
+                        float val = 0.0f;
+                        if (cx >= 0 && cy >= 0 && cx < www[k] && cy < wwh[k]) {
+                            val = win[cy * www[k] + cx];
+                        } else {
+                            const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
+                            if (gx >= 0 && gy >= 0) val = Gi[(size_t)gy * g.W + gx];
+                        }
+                        gv[dy][dx] = val;
+                    }
+                }
+                g00 = gv[0][0]; g01 = gv[0][1]; g02 = gv[0][2]; g10 = gv[1][0]; g11v = gv[1][1]; g12 = gv[1][2];
+                g20 = gv[2][0]; g21 = gv[2][1]; g22 = gv[2][2];
+            }
+            // dL/dwx = sum_dx Wx[dx] (sum_dy Ky[dy] G[dy][dx]),  dL/dwy = sum_dx Kx[dx] (sum_dy Wy[dy] G[dy][dx])
+            const float c0 = fmaf(kp.y, g20, fmaf(k0.y, g10, km.y * g00));
+            const float c1 = fmaf(kp.y, g21, fmaf(k0.y, g11v, km.y * g01));
+            const float c2 = fmaf(kp.y, g22, fmaf(k0.y, g12, km.y * g02));
+            const float d0 = fmaf(wy2, g20, fmaf(wy1, g10, wy0 * g00));
+            const float d1 = fmaf(wy2, g21, fmaf(wy1, g11v, wy0 * g01));
+            const float d2 = fmaf(wy2, g22, fmaf(wy1, g12, wy0 * g02));
+            const float gwx = fmaf(wx2, c2, fmaf(wx1, c1, wx0 * c0));
+            const float gwy = fmaf(kp.x, d2, fmaf(k0.x, d1, km.x * d0));
+            const float ndt = tauf[k] - tf;                                 // -(t - tau_r)
+            accx[k] = fmaf(ndt, gwx, accx[k]);
+            accy[k] = fmaf(ndt, gwy, accy[k]);
+        }
+    }
+    double sum11x = 0.0, sum11y = 0.0;
+#pragma unroll
+    for (int k = 0; k < RF; ++k)
+        if (r0 + k < g.R) { sum11x += (double)accx[k]; sum11y += (double)accy[k]; }
+    sum11x = block_sum(sum11x, red11);
+    sum11y = block_sum(sum11y, red11);
+    if (threadIdx.x == 0) {
+        double* dst = g11 + ((size_t)item * nrg + grp) * 2;
+        dst[0] = sum11x; dst[1] = sum11y;
     }
 }
 
@@ -1218,20 +1467,28 @@ __global__ __launch_bounds__(NT) void k_tv(Geom g, const double* __restrict__ Th
 
 // ------------------------------------------------------------------------------------------------
 // k_project: dL/dtheta[i,j,c] += sum_{y,x in tile} AH[y,i] AW[x,j] src[y,x,c]   (adjoint of k_theta).
-// grid (ntiles, B, nsrc): z = 0 projects the fp32 event gradient gTheta, z = 1 the fp64 TV gradient image.
-// One cell under the tile (2-DoF theta): block sum.  Several cells: every pixel adds its <= taps x taps contributions
-// into LDS cell accumulators (ds_add_f64), flushed with global_atomic_add_f64.  More cells than PROJ_CELLS: straight to HBM.
+// grid (ntiles, B, nsrc): z = 0 projects the i64 event gradient gTheta (and clears it: consumer-clears), z = 1 the fp64 TV
+// gradient image.  All sums are i64 fixed point (event part: scale grad_shift; TV part: tv_shift), so they do not depend on the
+// order of the atomics.  One cell under the tile: fp64 block sum in a fixed order, one i64 atomic.  Several cells: every pixel
+// adds its <= taps x taps contributions into LDS cell accumulators (ds_add_u64), flushed with global i64 atomics.  More cells
+// than PROJ_CELLS: straight to HBM.
 // ------------------------------------------------------------------------------------------------
 constexpr int PROJ_CELLS = 1024;
+// |tvg| <= 2 * 32 per pixel and component (two adjoint Scharr stencils of +-1 images); times H*W pixels, times <= 4 for the weights
+__host__ __device__ __forceinline__ int tv_shift(int H, int W) {
+    int e = 0;
+    while ((double)(1ull << e) <= 256.0 * (double)H * (double)W) ++e;
+    return 50 - e;
+}
 __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, int src0,
         const double* __restrict__ AH, const double* __restrict__ AW,
         const int2* __restrict__ rowtap, const int2* __restrict__ coltap,
-        const float* __restrict__ gTheta, const double* __restrict__ tvg,
-        double* __restrict__ gth_main, double* __restrict__ gth_tv)   // (B,cap) each, zeroed by k_theta
+        long long* __restrict__ gTheta, const double* __restrict__ tvg,
+        long long* __restrict__ gth_main, long long* __restrict__ gth_tv)   // (B,cap) each, zero on entry (k_final clears)
 {
     __shared__ double scratch[NWAVE];
     __shared__ int rng[4];
-    __shared__ double cells[PROJ_CELLS * 2];
+    __shared__ unsigned long long cells[PROJ_CELLS * 2];
     const int tile = blockIdx.x, b = blockIdx.y, src = blockIdx.z + src0;
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
@@ -1245,10 +1502,13 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
     __syncthreads();
     const int ilo = rng[0], ihi = rng[1], jlo = rng[2], jhi = rng[3];
     const int ni = max(ihi - ilo, 0), nj = max(jhi - jlo, 0), ncell = ni * nj;
-    double* __restrict__ out = (src == 0 ? gth_main : gth_tv) + (size_t)b * cap;
+    unsigned long long* __restrict__ out = reinterpret_cast<unsigned long long*>(src == 0 ? gth_main : gth_tv) + (size_t)b * cap;
+    // src 0: the pixel values already ARE integers at the accumulator scale, and the weights only shrink them: scale 1.
+    // src 1: fp64 TV gradient image -> fixed point at tv_shift.
+    const double scale = (src == 0) ? 1.0 : ldexp(1.0, tv_shift(g.H, g.W));
     const bool use_lds = (ncell > 1 && ncell <= PROJ_CELLS);
     if (use_lds) {
-        for (int i = threadIdx.x; i < ncell * 2; i += NT) cells[i] = 0.0;
+        for (int i = threadIdx.x; i < ncell * 2; i += NT) cells[i] = 0ull;
         __syncthreads();
     }
     double sx1 = 0.0, sy1 = 0.0;                    // single-cell path
@@ -1257,9 +1517,15 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
         if (y >= g.H || x >= g.W) continue;
         const size_t o = ((size_t)b * g.H * g.W + (size_t)y * g.W + x) * 2;
         double vx, vy;
-        if (src == 0) { vx = (double)gTheta[o]; vy = (double)gTheta[o + 1]; }
-        else { vx = tvg[o]; vy = tvg[o + 1]; }
-        if (vx == 0.0 && vy == 0.0) continue;
+        if (src == 0) {
+            const long long ix = gTheta[o], iy = gTheta[o + 1];
+            if (ix == 0 && iy == 0) continue;
+            gTheta[o] = 0; gTheta[o + 1] = 0;       // consumed: zero again for the next evaluation
+            vx = (double)ix; vy = (double)iy;       // exact: |.| < 2^51
+        } else {
+            vx = tvg[o] * scale; vy = tvg[o + 1] * scale;
+            if (vx == 0.0 && vy == 0.0) continue;
+        }
         const int2 rt = rowtap[y], ct = coltap[x];
         for (int i = rt.x; i < rt.y; ++i) {
             const double a = AH[(size_t)y * h + i];
@@ -1267,10 +1533,11 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
                 const double wt = a * AW[(size_t)x * w + j];
                 if (ncell == 1) { sx1 += wt * vx; sy1 += wt * vy; }
                 else if (use_lds) {
-                    double* c = cells + ((i - ilo) * nj + (j - jlo)) * 2;
-                    atomicAdd(c, wt * vx); atomicAdd(c + 1, wt * vy);
+                    unsigned long long* c = cells + ((i - ilo) * nj + (j - jlo)) * 2;
+                    atomicAdd(c, (unsigned long long)fix64(wt * vx)); atomicAdd(c + 1, (unsigned long long)fix64(wt * vy));
                 } else {
-                    atomicAdd(out + ((size_t)i * w + j) * 2, wt * vx); atomicAdd(out + ((size_t)i * w + j) * 2 + 1, wt * vy);
+                    atomicAdd(out + ((size_t)i * w + j) * 2, (unsigned long long)fix64(wt * vx));
+                    atomicAdd(out + ((size_t)i * w + j) * 2 + 1, (unsigned long long)fix64(wt * vy));
                 }
             }
         }
@@ -1279,14 +1546,14 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
         sx1 = block_sum(sx1, scratch);
         sy1 = block_sum(sy1, scratch);
         if (threadIdx.x == 0) {
-            if (sx1 != 0.0) atomicAdd(out + ((size_t)ilo * w + jlo) * 2, sx1);
-            if (sy1 != 0.0) atomicAdd(out + ((size_t)ilo * w + jlo) * 2 + 1, sy1);
+            if (sx1 != 0.0) atomicAdd(out + ((size_t)ilo * w + jlo) * 2, (unsigned long long)fix64(sx1));
+            if (sy1 != 0.0) atomicAdd(out + ((size_t)ilo * w + jlo) * 2 + 1, (unsigned long long)fix64(sy1));
         }
     } else if (use_lds) {
         __syncthreads();
         for (int i = threadIdx.x; i < ncell * 2; i += NT) {
-            const double v = cells[i];
-            if (v != 0.0) {
+            const unsigned long long v = cells[i];
+            if (v != 0ull) {
                 const int c = i & 1, ci = (i >> 1) / nj, cj = (i >> 1) % nj;
                 atomicAdd(out + ((size_t)(ilo + ci) * w + (jlo + cj)) * 2 + c, v);
             }
@@ -1303,7 +1570,9 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
         const StatPart* __restrict__ parts, const double* __restrict__ divparts, const double* __restrict__ tvparts,
         const double* __restrict__ tmm, const WinConst* __restrict__ wc,
         const double* __restrict__ g2parts,    // contrast energy partials from k_imgrad, or nullptr (then parts[].sG2 holds it)
-        const double* __restrict__ gth_main, const double* __restrict__ gth_tv, int gth_cap,
+        long long* __restrict__ gth_main, long long* __restrict__ gth_tv, int gth_cap,     // i64 cells (consumed and cleared here)
+        const double* __restrict__ g11, const int32_t* __restrict__ win_item0, int n_items, int g11_per_item,  // 2-DoF: per-workgroup partials of the gather kernel
+        const unsigned* __restrict__ gmax,
         OutScal* __restrict__ outs, double* __restrict__ grad_out, int want_grad)
 {
     __shared__ double scratch[NWAVE];
@@ -1387,27 +1656,48 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
     }
     __syncthreads();
     if (want_grad && !ep.identity) {
-        const double s = sh_tvscale;
+        const double s = sh_tvscale * ldexp(1.0, -tv_shift(g.H, g.W));
         const int n = ep.h * ep.w * 2;
-        for (int i = threadIdx.x; i < n; i += NT) {
-            double v = gth_main[(size_t)b * gth_cap + i];
-            if (n == 2)                                   // 2-DoF: k_gather spread its atomics over NSLOT11 slots
-                for (int sl = 1; sl < NSLOT11; ++sl) v += gth_main[(size_t)b * gth_cap + sl * SLOT11_STRIDE + i];
-            if (ep.use_tv_grad) v += s * gth_tv[(size_t)b * gth_cap + i];
-            grad_out[(size_t)b * n + i] = v;
+        if (n == 2) {
+            // 2-DoF: add the partials of this window's k_gather workgroups in index order (fixed strided order per thread, then
+            // the fixed tree of block_sum): bit-reproducible without any atomic
+            const int lo = win_item0[b], hi = (b + 1 < g.B) ? win_item0[b + 1] : n_items;
+            double sx = 0.0, sy = 0.0;
+            for (int k = lo * g11_per_item + threadIdx.x; k < hi * g11_per_item; k += NT) { sx += g11[2 * (size_t)k]; sy += g11[2 * (size_t)k + 1]; }
+            sx = block_sum(sx, scratch);
+            sy = block_sum(sy, scratch);
+            if (threadIdx.x == 0) {
+                if (ep.use_tv_grad) {
+                    sx += s * (double)gth_tv[(size_t)b * gth_cap]; sy += s * (double)gth_tv[(size_t)b * gth_cap + 1];
+                    gth_tv[(size_t)b * gth_cap] = 0; gth_tv[(size_t)b * gth_cap + 1] = 0;
+                }
+                grad_out[(size_t)b * 2] = sx; grad_out[(size_t)b * 2 + 1] = sy;
+            }
+        } else {
+            const double inv = ldexp(1.0, -grad_shift(c, gmax + b * g.R, g.R));
+            for (int i = threadIdx.x; i < n; i += NT) {
+                double v = (double)gth_main[(size_t)b * gth_cap + i] * inv;
+                gth_main[(size_t)b * gth_cap + i] = 0;
+                if (ep.use_tv_grad) { v += s * (double)gth_tv[(size_t)b * gth_cap + i]; gth_tv[(size_t)b * gth_cap + i] = 0; }
+                grad_out[(size_t)b * n + i] = v;
+            }
         }
     }
 }
 
-// dense (identity resample) gradient: grad = (double)gTheta + tv_scale * tvg.  grid-stride, grid (nblk, B)
-__global__ void k_final_dense(Geom g, int use_tv, const float* __restrict__ gTheta, const double* __restrict__ tvg,
+// dense (identity resample) gradient: grad = gTheta * 2^-eg + tv_scale * tvg; consumes (clears) the i64 image.  grid-stride, grid (nblk, B)
+__global__ void k_final_dense(Geom g, int use_tv, long long* __restrict__ gTheta, const double* __restrict__ tvg,
+                              const WinConst* __restrict__ wc, const unsigned* __restrict__ gmax,
                               const OutScal* __restrict__ outs, double* __restrict__ grad_out)
 {
     const int b = blockIdx.y;
     const size_t n = (size_t)g.H * g.W * 2;
     const double s = outs[b].tv_scale;
+    const double inv = ldexp(1.0, -grad_shift(wc[b], gmax + b * g.R, g.R));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        double v = (double)gTheta[b * n + i];
+        const long long q = gTheta[b * n + i];
+        if (q != 0) gTheta[b * n + i] = 0;
+        double v = (double)q * inv;
         if (use_tv) v += s * tvg[b * n + i];
         grad_out[b * n + i] = v;
     }

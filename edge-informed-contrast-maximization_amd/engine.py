@@ -20,6 +20,24 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def as_int16_coords(a, what='coordinates'):
+    """Event coordinates as int16, the reference's wire format.  Integer arrays are range-checked and cast; float arrays
+    (e.g. rectified coordinates handed straight to loss_func) are rounded half-to-even first, like ``jnp.round(xs).astype(int16)``
+    in per_pix_warp (/root/reference/src/eincm/event_warpers.py:29-30).  Values outside the int16 range raise instead of wrapping."""
+    a = np.asarray(a)
+    if a.dtype == np.int16:
+        return a
+    if a.dtype.kind not in 'iuf':
+        raise TypeError(f'{what} must be integer or floating point, got {a.dtype}')
+    if a.dtype.kind == 'f':
+        if a.size and not np.all(np.isfinite(a)):
+            raise ValueError(f'{what} contain non-finite values')
+        a = np.rint(a)
+    if a.size and (a.min() < -32768 or a.max() > 32767):
+        raise ValueError(f'{what} outside the int16 range [-32768, 32767]')
+    return a.astype(np.int16)
+
+
 def make_params(alpha, beta, gamma, delta, cur_pyr_lvl, method='bilinear', contrast_kind=L.CONTRAST_GRAD_MAG,
                 full_aux=False):
     if isinstance(method, str):
@@ -84,8 +102,8 @@ class Engine:
         B = len(windows)
         R = len(np.atleast_1d(windows[0][4]))
         n = np.array([len(w[0]) for w in windows], dtype=np.int64)
-        xs = np.ascontiguousarray(np.concatenate([np.asarray(w[0]).astype(np.int16, copy=False) for w in windows]))
-        ys = np.ascontiguousarray(np.concatenate([np.asarray(w[1]).astype(np.int16, copy=False) for w in windows]))
+        xs = np.ascontiguousarray(np.concatenate([as_int16_coords(w[0], 'xs') for w in windows]))
+        ys = np.ascontiguousarray(np.concatenate([as_int16_coords(w[1], 'ys') for w in windows]))
         ts = np.ascontiguousarray(np.concatenate([np.asarray(w[2], dtype=np.float64) for w in windows]))
         edges = np.ascontiguousarray(np.stack([np.asarray(w[3], dtype=np.float64) for w in windows]))
         edge_ts = np.ascontiguousarray(np.stack([np.atleast_1d(np.asarray(w[4], dtype=np.float64)) for w in windows]))
@@ -132,12 +150,16 @@ class Engine:
             th = th[None]
         if th.ndim != 4 or th.shape[0] != self.B or th.shape[3] != 2:
             raise ValueError(f'theta must be ({self.B},h,w,2), got {th.shape}')
-        self._async = (th.shape, bool(want_grad))
+        self._async = None
         self._check(self._lib.eincm_loss_grad_async(self._ctx, th.ctypes.data, th.shape[1], th.shape[2], C.byref(params),
                                                     1 if want_grad else 0))
+        self._async = (th.shape, bool(want_grad))
 
     def loss_grad_wait(self, want_aux=False, allow_nonfinite=True):
+        if getattr(self, '_async', None) is None:
+            raise EincmError(L.ERR_STATE, 'eincm_loss_grad_wait without eincm_loss_grad_async')
         shape, want_grad = self._async
+        self._async = None
         value = np.empty(self.B, dtype=np.float64)
         grad = np.empty(shape, dtype=np.float64) if want_grad else None
         aux = (L.Aux * self.B)() if want_aux else None
@@ -184,8 +206,14 @@ class Engine:
         return torch.as_tensor(_View(), device=torch.device('cuda', torch.cuda.current_device()))
 
     def iwe_tensor(self):
-        """torch view of the IWE stack (B,R,H,W) float32 in HBM, for an RCCL all-reduce between the two halves."""
-        return self._device_view(self._lib.eincm_iwe_device_ptr, '<f4', 4, (self.B, self.R, self.H, self.W))
+        """torch view of the IWE accumulator (B,R,H,W) in HBM, for an RCCL all-reduce(sum) between the two halves.  The engine sums
+        the IWE in u32 fixed point (exact, order-independent); the view is int32 because RCCL / gloo reduce signed integers and
+        two's-complement addition is the same operation."""
+        return self._device_view(self._lib.eincm_iwe_device_ptr, '<i4', 4, (self.B, self.R, self.H, self.W))
+
+    def set_iwe_scale_events(self, n_events_per_window):
+        """Event-sharded mode: the fixed-point scale of the IWE accumulator must hold the events of ALL shards of a window."""
+        self._check(self._lib.eincm_set_iwe_scale_events(self._ctx, int(n_events_per_window)))
 
     def mask_tensor(self):
         """torch view of the event-presence mask (B,H,W) uint8."""
@@ -371,10 +399,24 @@ class EngineGroup:
             th = th[None]
         if th.shape[0] != self.B:
             raise ValueError(f'theta must be ({self.B},h,w,2), got {th.shape}')
-        live = list(zip(self.engines, self._slices))
-        for e, sl in live:
-            e.loss_grad_async(th[sl], params, want_grad)
-        outs = [e.loss_grad_wait(want_aux, allow_nonfinite) for e, _ in live]
+        # Every context that was launched is waited for before anything is raised: a context left in flight would refuse
+        # every later call (EINCM_ERR_STATE) and the group has no other drain.  The first error wins.
+        launched, outs, first_err = [], [], None
+        try:
+            for e, sl in zip(self.engines, self._slices):
+                e.loss_grad_async(th[sl], params, want_grad)
+                launched.append(e)
+        except Exception as err:          # noqa: BLE001 - re-raised below, after the drain
+            first_err = err
+        for e in launched:
+            try:
+                outs.append(e.loss_grad_wait(want_aux, allow_nonfinite))
+            except Exception as err:      # noqa: BLE001
+                outs.append(None)
+                if first_err is None:
+                    first_err = err
+        if first_err is not None:
+            raise first_err
         value = np.concatenate([o[0] for o in outs])
         grad = np.concatenate([o[1] for o in outs]) if want_grad else None
         aux = [a for o in outs for a in o[2]] if want_aux else None

@@ -12,7 +12,9 @@ engine cannot be traced, so the gradient is exposed explicitly as ``value_and_gr
 ``solver.ScipyMinimize``.
 
 The event window is staged on the GPU once and reused for every evaluation, like the reference's closed-over
-device-resident ``*args``: engines are cached by the identity of the (xs, ys, ts, edges, edge_ts) arrays.
+device-resident ``*args``: engines are cached by the identity of the (xs, ys, ts, edges, edge_ts) arrays.  JAX arrays are
+immutable, numpy arrays are not: an in-place edit of a cached array is caught by a cheap content fingerprint (a strided
+sample of every array) and the window is staged again.
 """
 import weakref
 
@@ -29,15 +31,31 @@ def _as_np(a):
     return a if isinstance(a, np.ndarray) else np.asarray(a)
 
 
+def _fingerprint(arrs):
+    """Content check of the cached arrays: <= 4096 strided samples of each plus first/last element, as bytes."""
+    parts = []
+    for a in arrs:
+        f = a.reshape(-1)
+        if f.size:
+            parts.append(np.ascontiguousarray(f[::max(1, f.size // 4096)]).tobytes())
+            parts.append(f[-1:].tobytes())
+    return hash(tuple(parts))
+
+
 def engine_for(xs, ys, ts, edges, edge_ts, sensor_size, device=0):
-    """Engine holding this window (staged on first use; reused while the same array objects are passed)."""
+    """Engine holding this window (staged on first use; reused while the same, unmodified array objects are passed)."""
     arrs = tuple(_as_np(a) for a in (xs, ys, ts, edges, edge_ts))
+    fp = _fingerprint(arrs)
     key = (tuple(int(s) for s in sensor_size), device) + tuple((a.shape, a.dtype.str) for a in arrs)
     for i, (refs, k, eng) in enumerate(_CACHE):
-        if k == key and all(r() is a for r, a in zip(refs, arrs)):
+        if k[:-1] == key and all(r() is a for r, a in zip(refs, arrs)):
+            if k[-1] != fp:                       # same objects, edited in place: stage again
+                _CACHE.pop(i)[2].close()
+                break
             if i:
                 _CACHE.insert(0, _CACHE.pop(i))
             return eng
+    key = key + (fp,)
     eng = Engine(sensor_size, max_events_total=max(len(arrs[0]), 1), max_refs=max(len(np.atleast_1d(arrs[4])), 1),
                  max_windows=1, device=device)
     eng.set_window(*arrs)

@@ -64,6 +64,7 @@ def stage_datasample(datasample, edges):
     ev = datasample['events']
     start_time, end_time = datasample['eval_ts_us'] if 'eval_ts_us' in datasample else datasample['eval_ts']
     ts, image_ts = normalize_times(ev['t'], datasample['image_ts'], float(start_time), float(end_time))
-    xs = np.ascontiguousarray(ev['x']).astype(np.int16)
-    ys = np.ascontiguousarray(ev['y']).astype(np.int16)
+    from .engine import as_int16_coords       # rounds float coordinates half-to-even (event_warpers.py:29-30), range-checks
+    xs = np.ascontiguousarray(as_int16_coords(ev['x'], 'x'))
+    ys = np.ascontiguousarray(as_int16_coords(ev['y'], 'y'))
     return xs, ys, ts, normalize_edges(edges), image_ts

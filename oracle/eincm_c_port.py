@@ -22,6 +22,9 @@ def load(build=True):
         lib.eincm_ref_loss_grad.restype = C.c_int
         lib.eincm_ref_loss_grad.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int16), C.POINTER(C.c_int16), dp, dp, dp,
                                             dp, C.c_double, C.c_double, dp, dp, C.c_int]
+        lib.eincm_ref_loss_grad_ex.restype = C.c_int
+        lib.eincm_ref_loss_grad_ex.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int16), C.POINTER(C.c_int16), dp, dp, dp,
+                                               dp, C.c_double, C.c_double, dp, dp, dp, dp, C.c_int]
         lib.eincm_ref_max_threads.restype = C.c_int
         _LIB = lib
     return _LIB
@@ -31,8 +34,10 @@ def max_threads():
     return int(load().eincm_ref_max_threads())
 
 
-def loss_and_grad(theta, xs, ys, ts, edges, edge_ts, alpha, beta, sensor_size, method='bilinear', nthreads=None, want_grad=True):
-    """(value, grad (h,w,2)) of loss_func with gamma = delta = 0 (any cur_pyr_lvl), float64, `nthreads` OpenMP threads."""
+def loss_and_grad(theta, xs, ys, ts, edges, edge_ts, alpha, beta, sensor_size, method='bilinear', nthreads=None, want_grad=True,
+                  return_images=False):
+    """(value, grad (h,w,2)) of loss_func with gamma = delta = 0 (any cur_pyr_lvl), float64, `nthreads` OpenMP threads.
+    return_images: also return {'iwes': (R,H,W), 'G': (R,H,W) dL/dIWE (None without a gradient)}."""
     lib = load()
     H, W = sensor_size
     theta = np.asarray(theta, dtype=np.float64)
@@ -43,10 +48,17 @@ def loss_and_grad(theta, xs, ys, ts, edges, edge_ts, alpha, beta, sensor_size, m
     val = C.c_double(0.0)
     g = np.zeros((H, W, 2)) if want_grad else None
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-    rc = lib.eincm_ref_loss_grad(H, W, len(xs), len(edge_ts), xs.ctypes.data_as(C.POINTER(C.c_int16)),
-                                 ys.ctypes.data_as(C.POINTER(C.c_int16)), dp(ts), dp(edges), dp(edge_ts), dp(Theta), float(alpha),
-                                 float(beta), C.byref(val), dp(g) if want_grad else None, int(nthreads or max_threads()))
+    R = len(edge_ts)
+    iwes = np.zeros((R, H, W)) if return_images else None
+    G = np.zeros((R, H, W)) if (return_images and want_grad) else None
+    rc = lib.eincm_ref_loss_grad_ex(H, W, len(xs), R, xs.ctypes.data_as(C.POINTER(C.c_int16)),
+                                    ys.ctypes.data_as(C.POINTER(C.c_int16)), dp(ts), dp(edges), dp(edge_ts), dp(Theta), float(alpha),
+                                    float(beta), C.byref(val), dp(g) if want_grad else None,
+                                    dp(iwes) if iwes is not None else None, dp(G) if G is not None else None,
+                                    int(nthreads or max_threads()))
     if rc:
         raise MemoryError('eincm_ref_loss_grad failed')
     grad = O.scale_theta_adjoint(g, theta.shape, method) if want_grad else None
+    if return_images:
+        return val.value, grad, {'iwes': iwes, 'G': G}
     return val.value, grad

@@ -91,10 +91,12 @@ static void minmax(const double* a, size_t n, double* mn, double* mx) {
     *mn = lo; *mx = hi;
 }
 
-/* returns 0 on success.  g_Theta (H,W,2) may be NULL (forward only). */
-int eincm_ref_loss_grad(int H, int W, int64_t N, int R, const int16_t* xs, const int16_t* ys, const double* ts,
-                        const double* edges, const double* edge_ts, const double* Theta, double alpha, double beta,
-                        double* value, double* g_Theta, int nthreads) {
+/* returns 0 on success.  g_Theta (H,W,2) may be NULL (forward only).  iwes_out (R,H,W) and G_out (R,H,W; dL/dIWE, only
+ * filled when g_Theta is given) may be NULL: they expose the image of warped events and its cotangent so that the
+ * full-size GPU parity tests can compare images, not only scalars. */
+int eincm_ref_loss_grad_ex(int H, int W, int64_t N, int R, const int16_t* xs, const int16_t* ys, const double* ts,
+                           const double* edges, const double* edge_ts, const double* Theta, double alpha, double beta,
+                           double* value, double* g_Theta, double* iwes_out, double* G_out, int nthreads) {
     const size_t HW = (size_t)H * W;
     int nt = nthreads > 0 ? nthreads : 1;
 #ifndef _OPENMP
@@ -138,6 +140,7 @@ int eincm_ref_loss_grad(int H, int W, int64_t N, int R, const int16_t* xs, const
             wy[e] = (double)ys[e] - Theta[o + 1] * dt * 1.0;
         }
         splat(wx, wy, N, H, W, I, scratch, nt);
+        if (iwes_out) memcpy(iwes_out + (size_t)r * HW, I, sizeof(double) * HW);
         double m, M;
         minmax(I, HW, &m, &M);
         const double D = M - m + EPSN;
@@ -184,6 +187,7 @@ int eincm_ref_loss_grad(int H, int W, int64_t N, int R, const int16_t* xs, const
                 if (I[p] == M) g += dM / cnt_M;
                 G[p] = g;
             }
+        if (G_out) memcpy(G_out + (size_t)r * HW, G, sizeof(double) * HW);
         /* gather + accumulate per source pixel: private accumulators per thread, then reduce */
         memset(scratch, 0, sizeof(double) * HW * 2 * nt);
 #pragma omp parallel num_threads(nt)
@@ -226,6 +230,12 @@ int eincm_ref_loss_grad(int H, int W, int64_t N, int R, const int16_t* xs, const
     *value = alpha * (-(sum_con / R)) + beta * (-(sum_corr / R));
     free(wx); free(wy); free(I0); free(I); free(G); free(gx); free(gy); free(n0); free(scratch); free(w);
     return 0;
+}
+
+int eincm_ref_loss_grad(int H, int W, int64_t N, int R, const int16_t* xs, const int16_t* ys, const double* ts,
+                        const double* edges, const double* edge_ts, const double* Theta, double alpha, double beta,
+                        double* value, double* g_Theta, int nthreads) {
+    return eincm_ref_loss_grad_ex(H, W, N, R, xs, ys, ts, edges, edge_ts, Theta, alpha, beta, value, g_Theta, NULL, NULL, nthreads);
 }
 
 int eincm_ref_max_threads(void) {

@@ -1,0 +1,94 @@
+"""Float parity of the HIP path at the sizes the metric is quoted on (BASELINE.json configs C2..C5), against the C / OpenMP fp64
+port of the oracle (oracle/eincm_ref.c; itself checked to 1e-12 against the numpy oracle in tests/test_oracle_c_port.py —
+the numpy oracle needs minutes at these sizes, the port a fraction of a second on the box's cores).
+
+Compared at every size: loss, gradient (max-norm relative), the IWE stack and the dL/dIWE images, all at the north-star
+tolerance 1e-5 (relative; images and gradients max-norm relative).  The C port covers gamma = delta = 0, which is what the
+bench evaluates; the TV / divergence terms are image-sized work whose parity does not depend on the event count
+(tests/test_gpu_parity.py covers them).
+
+Follows /root/reference/src/eincm/losses.py:108-205, src/utils/event_utils.py:31-61 (via the oracle restatement).
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import eincm_c_port as CP
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+synth = importlib.import_module('edge-informed-contrast-maximization_amd.synth')
+engine = importlib.import_module('edge-informed-contrast-maximization_amd.engine')
+
+NTHREADS = min(os.cpu_count() or 1, 16)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def win_args(win):
+    return (win['xs'], win['ys'], win['ts'], win['edges'], win['edge_ts'])
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _lib(built_lib):
+    return built_lib
+
+
+def check_window(eng, b, th, win, alpha, beta, v, g, iwes, G):
+    H, W = win['sensor_size']
+    v_ref, g_ref, im = CP.loss_and_grad(th, *win_args(win), alpha, beta, (H, W), nthreads=NTHREADS, return_images=True)
+    assert abs(v[b] - v_ref) <= TOL * abs(v_ref), (b, v[b], v_ref)
+    assert rel(g[b], g_ref) <= TOL, (b, rel(g[b], g_ref))
+    assert rel(iwes[b], im['iwes']) <= TOL, (b, rel(iwes[b], im['iwes']))
+    assert rel(G[b], im['G']) <= TOL, (b, rel(G[b], im['G']))
+
+
+FULL = [
+    # id, (H,W), N, R, theta, flow, alpha, beta, lvl      (C2/C4 window shape; C3; C5)
+    ('mvsec_1e6_2dof', (260, 346), 1_000_000, 5, (1, 1), 'constant', 20.0, 35.0, 4),
+    ('mvsec_1e6_pyr16', (260, 346), 1_000_000, 5, (16, 16), 'smooth', 20.0, 35.0, 0),
+    ('dsec_1e6_dense', (480, 640), 1_000_000, 3, 'dense', 'smooth', 2000.0, 4000.0, 0),
+    ('dsec_1e7_pyr16', (480, 640), 10_000_000, 3, (16, 16), 'smooth', 2000.0, 4000.0, 0),
+]
+
+
+@pytest.mark.parametrize('case', FULL, ids=[c[0] for c in FULL])
+def test_full_size_float_parity(case):
+    _, (H, W), N, R, hw, flow, al, be, lvl = case
+    win = synth.make_window(21, (H, W), N, R, flow=flow, flow_mag=20.0)
+    if hw == 'dense':
+        th = win['flow_gt'] * np.random.default_rng(3).uniform(0.5, 1.5, (H, W, 2))
+    else:
+        th = synth.theta_near_truth(21, win, hw)
+    with engine.Engine((H, W), N, max_refs=R) as eng:
+        eng.set_window(*win_args(win))
+        v, g, _ = eng.loss_grad(th, engine.make_params(al, be, 0.0, 0.0, lvl))
+        check_window(eng, 0, th, win, al, be, v, g, eng.iwes(), eng.image_grad())
+
+
+def test_bench_batch_c4_share():
+    """The bench workload itself: the per-GPU share of C4, 8 windows x 1e6 events (260x346, R = 5, 2-DoF theta) staged in ONE
+    context and evaluated by one call; every window against its own C-port value.  Same seeds and theta recipe as bench.py."""
+    H, W, B, N, R = 260, 346, 8, 1_000_000, 5
+    wins = [synth.make_window(b, (H, W), N, R, flow='constant', flow_mag=20.0) for b in range(B)]
+    th = np.stack([synth.theta_near_truth(b, wn, (1, 1)) for b, wn in enumerate(wins)]) * 1.01
+    with engine.Engine((H, W), B * N, max_refs=R, max_windows=B) as eng:
+        eng.set_windows([win_args(wn) for wn in wins])
+        v, g, _ = eng.loss_grad(th, engine.make_params(20.0, 35.0, 0.0, 0.0, 4))
+        iwes, G = eng.iwes(), eng.image_grad()
+        for b in range(B):
+            check_window(eng, b, th[b], wins[b], 20.0, 35.0, v, g, iwes, G)
+        # the same windows one at a time give the same numbers (up to the accumulation order of the float images)
+        v1 = []
+    with engine.Engine((H, W), N, max_refs=R) as e1:
+        for b in (0, B - 1):
+            e1.set_window(*win_args(wins[b]))
+            vb, gb, _ = e1.loss_grad(th[b], engine.make_params(20.0, 35.0, 0.0, 0.0, 4))
+            assert vb[0] == pytest.approx(v[b], rel=1e-6) and rel(gb[0], g[b]) <= 1e-5

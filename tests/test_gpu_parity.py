@@ -532,3 +532,21 @@ def test_half_pixel_ties_and_near_ties():
             for r in range(R):
                 wx, wy = O.per_pix_warp(Theta, xs, ys, ts, edge_ts[r])
                 assert np.array_equal(cnt[r], O.rounded_count_image(wx, wy, (H, W))), theta
+
+
+def test_long_splat_segments_use_two_lds_windows(monkeypatch):
+    """EINCM_SEG_SPLAT > EINCM_CHUNK selects k_splat's multi-chunk form (u32 chunk window + f32 segment window in LDS).  With a
+    large-flow 16x16 theta the per-evaluation window capacity is raised; it must stay within the 64 KiB of dynamic LDS a launch
+    gets (2 x 6912 x 4 B + the 16 KiB Theta tile did not)."""
+    monkeypatch.setenv('EINCM_SEG_SPLAT', '8192')
+    monkeypatch.setenv('EINCM_CHUNK', '4096')
+    H, W, N, R = 130, 170, 150000, 3
+    win = synth.make_window(17, (H, W), N, R, flow='smooth', flow_mag=90.0)
+    th = synth.theta_near_truth(17, win, (16, 16))
+    v_ref, g_ref, aux = O.loss_and_grad(th, *win_args(win), 20.0, 35.0, 0.0, 0.0, 0, 5, (H, W), return_intermediates=True)
+    with engine.Engine((H, W), N, max_refs=R) as eng:
+        eng.set_window(*win_args(win))
+        v, g, _ = eng.loss_grad(th, engine.make_params(20.0, 35.0, 0.0, 0.0, 0))
+        assert abs(v[0] - v_ref) <= TOL * abs(v_ref)
+        assert rel(g[0], g_ref) <= TOL
+        assert rel(eng.iwes()[0], aux['_iwes']) <= TOL

@@ -133,6 +133,26 @@ def test_time_normalisation_and_stage():
     np.testing.assert_allclose(ets, [0.0, 1.0])
 
 
+def test_coordinates_round_like_the_reference_and_are_range_checked():
+    """per_pix_warp casts jnp.round(xs) to int16 (event_warpers.py:29-30): half-to-even, never truncation; out-of-range
+    values raise instead of wrapping silently."""
+    engine = importlib.import_module('edge-informed-contrast-maximization_amd.engine')
+    a = engine.as_int16_coords(np.array([0.5, 1.5, 2.5, 3.49, 3.51, 10.0]))
+    assert a.dtype == np.int16 and a.tolist() == [0, 2, 2, 3, 4, 10]
+    assert engine.as_int16_coords(np.array([3, 4], dtype=np.int64)).dtype == np.int16
+    b = np.array([7, 8], dtype=np.int16)
+    assert engine.as_int16_coords(b) is b
+    for bad in (np.array([40000]), np.array([-40000.0]), np.array([1e9])):
+        with pytest.raises(ValueError, match='int16'):
+            engine.as_int16_coords(bad)
+    with pytest.raises(ValueError, match='non-finite'):
+        engine.as_int16_coords(np.array([np.nan]))
+    ds = {'events': {'x': np.array([0.5, 1.5, 2.6]), 'y': np.array([4.0, 5.0, 6.0]), 't': np.array([0.0, 1.0, 2.0])},
+          'image_ts': np.array([0.0, 2.0]), 'eval_ts': (0.0, 2.0)}
+    xs, ys, *_ = staging.stage_datasample(ds, [np.eye(2), np.eye(2)])
+    assert xs.tolist() == [0, 2, 3] and ys.tolist() == [4, 5, 6]
+
+
 def test_yaml_config_reader(tmp_path):
     """Same constructs as src/experiments/e00/configs: defaults groups, ${a.b} interpolation, nested ${..${..}}, divide."""
     (tmp_path / 'dataset').mkdir()
