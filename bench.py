@@ -1,14 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — EINCM loss+grad throughput on MI355X (contract: see the task statement / DESIGN.md "Measurement").
 
-A step = ONE value_and_grad(loss_func) evaluation of this rank's batch of independent event windows (inputs already
-resident in HBM), followed for N > 1 by the RCCL all-reduce of the scalar batch loss.  Workload at N = 1: the
-per-GPU share of BASELINE.json config C4 — 8 MVSEC-shape windows (260x346), 1e6 events each, 5 reference times,
-2-DoF theta, full EINCM objective (contrast + edge correlation), alpha=20 beta=35 — which is the configuration the
-metric "warped-events/sec/GPU ... 1e6 events @ 346x260" is quoted on.  Weak scaling: every rank holds its own 8 windows.
+Two decompositions, one JSON line each:
+
+--mode windows (default; BASELINE.json config C4, the configuration the metric "warped-events/sec/GPU ... 1e6 events @ 346x260"
+    is quoted on).  A step = ONE value_and_grad(loss_func) evaluation of this rank's batch of independent event windows, inputs
+    resident in HBM, theta changed every call.  Workload per GPU: 8 MVSEC-shape windows (260x346), 1e6 events each, 5 reference
+    times, 2-DoF theta, full EINCM objective (contrast + edge correlation), alpha=20 beta=35.  Weak scaling: every rank holds its
+    own 8 windows.  Windows are independent objects, so there is NO data-path collective; for N > 1 the timed step additionally
+    all-reduces the scalar batch loss over RCCL (the one collective north_star names), issued asynchronously so that it overlaps
+    the next step; the same K steps are also timed without it and reported beside (`no_collective`).
+
+--mode event-sharded (BASELINE.json config C5: 480x640, 1e7 events, R = 3, theta pyramid 1..16).  The events of ONE window are
+    split over the ranks (sharding.ShardedEngine): per evaluation one all-reduce(sum) of the int64 IWE accumulator in HBM and one
+    of the small gradient.  A step = one loss+grad evaluation at pyramid level (k mod 5); strong scaling (total work fixed).
+    A 50-iteration BFGS solve over the pyramid is timed beside it (`solve_50_iters_s`).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+    EINCM_BENCH_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 --mode event-sharded   (1-GPU rehearsal)
 """
 import argparse
 import importlib
@@ -23,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+ROUND = 'r02'
 
 
 def algorithmic_bytes(N, R, H, W, dense_theta):
@@ -31,32 +42,44 @@ def algorithmic_bytes(N, R, H, W, dense_theta):
     return 2 * 8 * N + R * H * W * 4 * 5 + (H * W * 2 * 4 * 2 if dense_theta else 0)
 
 
-def splat_algorithmic_bytes(N, R, H, W):
-    """Dominant kernel (k_splat): events in once (8 B each) + the R IWE images out (fp32)."""
+def event_kernel_algorithmic_bytes(N, R, H, W):
+    """One event kernel (k_splat: events in once, 8 B each, + the R IWE images out; k_gather: events in once + the R dL/dIWE
+    images in): 8 N + 4 R H W per window."""
     return 8 * N + 4 * R * H * W
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--mode', choices=('windows', 'event-sharded'), default='windows')
     ap.add_argument('--windows-per-gpu', type=int, default=8)
-    ap.add_argument('--events', type=int, default=1_000_000)
-    ap.add_argument('--refs', type=int, default=5)
-    ap.add_argument('--sensor', type=str, default='260x346')
-    ap.add_argument('--theta', type=str, default='1x1', help='hxw of theta, or "dense"')
+    ap.add_argument('--events', type=int, default=None, help='events per window (default 1e6; event-sharded: 1e7)')
+    ap.add_argument('--refs', type=int, default=None, help='reference times (default 5; event-sharded: 3)')
+    ap.add_argument('--sensor', type=str, default=None, help='HxW (default 260x346; event-sharded: 480x640)')
+    ap.add_argument('--theta', type=str, default='1x1', help='hxw of theta, or "dense" (windows mode)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-latency', action='store_true')
+    ap.add_argument('--solve-iters', type=int, default=50, help='event-sharded: BFGS iterations of the end-to-end leg (0 = skip)')
     ap.add_argument('--groups', type=int, default=1, help='contexts (HIP streams) the windows of a rank are spread over')
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
+    sharded = a.mode == 'event-sharded'
+    if a.events is None:
+        a.events = 10_000_000 if sharded else 1_000_000
+    if a.refs is None:
+        a.refs = 3 if sharded else 5
+    if a.sensor is None:
+        a.sensor = '480x640' if sharded else '260x346'
+    return a
 
+
+def init_dist(a):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    if world != a.gpus and world == 1 and a.gpus > 1:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
     import torch
     import torch.distributed as dist
     ndev = max(torch.cuda.device_count(), 1)
@@ -71,7 +94,6 @@ def main():
             dist.init_process_group(backend='nccl', device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-
     import __graft_entry__ as ge
     if world > 1:
         # one builder per node (hipcc writes the .so in place); everyone else loads it after the barrier
@@ -79,9 +101,32 @@ def main():
             ge.build()
         dist.barrier()
     ge.build()
+    return rank, world, dev_index, dev, red_dev, backend
+
+
+def load_traffic(workload):
+    """HBM bytes per launch of the two event kernels from the committed PMC passes of this round (profiles/traffic.json)."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get(workload, {})
+    except Exception:
+        return {}
+
+
+def kernel_roofline(name, ms, alg_bytes, traffic):
+    ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {'kernel': name, 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS,
+            'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms, 'traffic': traffic}
+
+
+# =====================================================================================================================
+# mode: independent windows (C4)
+# =====================================================================================================================
+def bench_windows(a):
+    import torch
+    import torch.distributed as dist
+    rank, world, dev_index, dev, red_dev, backend = init_dist(a)
     synth = importlib.import_module('edge-informed-contrast-maximization_amd.synth')
     engine = importlib.import_module('edge-informed-contrast-maximization_amd.engine')
-    sharding = importlib.import_module('edge-informed-contrast-maximization_amd.sharding')
 
     H, W = (int(v) for v in a.sensor.split('x'))
     B, N, R = a.windows_per_gpu, a.events, a.refs
@@ -96,7 +141,6 @@ def main():
         base = np.stack([wn['flow_gt'] for wn in wins])
     else:
         base = np.stack([synth.theta_near_truth(1000 * rank + b, wn, (h, w)) for b, wn in enumerate(wins)])
-    n_theta = a.steps + a.warmup
     if a.groups > 1:
         eng = engine.EngineGroup((H, W), B * N, max_refs=R, max_windows=B, n_groups=a.groups, device=dev_index, timing='dominant')
     else:
@@ -109,46 +153,56 @@ def main():
     def theta_at(k):                    # theta changes every call: nothing but the window constants is reusable
         return base * (1.0 + 0.01 * ((k % 7) - 3))
 
-    def step(k):
-        # windows are independent objects: every rank evaluates its own, and nothing is exchanged on the data path
-        # (each window's loss feeds its own solver).  The only collectives are the barriers around the timed region,
-        # the max over ranks of the elapsed time, and one untimed all-reduce of the last batch loss below.
-        v, g, _ = eng.loss_grad(theta_at(k), p)
-        return float(v.sum()), v, g
+    def timed_region(n_steps, k0, with_allreduce):
+        """n_steps evaluations between two barriers; returns (elapsed max over ranks, last values, last grads, last all-reduced loss)."""
+        pending, total = [], None
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if hasattr(eng, 'timings_total'):
+            eng.timings_total(reset=True)     # the engine sums the per-launch HIP-event times of the timed region itself
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            v, g, _ = eng.loss_grad(theta_at(k0 + k), p)
+            if with_allreduce:
+                # the scalar batch loss of this step, summed over ranks; asynchronous: it overlaps the next step's kernels
+                t = torch.tensor([float(v.sum())], dtype=torch.float64, device=red_dev)
+                pending.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t))
+                if len(pending) > 2:
+                    wk, tt = pending.pop(0)
+                    wk.wait()
+        for wk, tt in pending:
+            wk.wait()
+            total = tt
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, v, g, (float(total.item()) if total is not None else float(v.sum()))
 
     # bring the GPU to its working clocks before anything is measured: a cold device runs the first ~100 ms about 8 % slower,
     # which a 3-step warm-up (1 ms) does not cover.  Untimed preparation, like staging; then the W warm-up steps of the contract.
     t_spin = time.perf_counter() + 0.3
     k = 0
     while time.perf_counter() < t_spin:
-        step(k); k += 1
+        eng.loss_grad(theta_at(k), p); k += 1
     for k in range(a.warmup):
-        step(k)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if hasattr(eng, 'timings_total'):
-        eng.timings_total(reset=True)         # the engine sums the per-launch HIP-event times of the timed region itself
+        eng.loss_grad(theta_at(k), p)
+
+    elapsed, v, g, batch_loss_all = timed_region(a.steps, a.warmup, with_allreduce=world > 1)
     stage_acc = {}
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        tot, v, g = step(a.warmup + k)
-        if a.groups > 1:
-            for kk, vv in eng.timings().items():
-                stage_acc[kk] = stage_acc.get(kk, 0.0) + vv
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
     if a.groups <= 1:
         stage_acc, n_timed = eng.timings_total()
         assert n_timed == a.steps, (n_timed, a.steps)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     assert np.all(np.isfinite(v)) and np.all(np.isfinite(g)), 'non-finite loss/grad in the timed region'
-    batch_loss_all_ranks = sharding.allreduce_batch_loss(v, red_dev) if world > 1 else float(v.sum())     # untimed
+    no_coll = None
+    if world > 1:          # the same K steps without the collective, for comparison (not the headline)
+        e2, _, _, _ = timed_region(a.steps, a.warmup, with_allreduce=False)
+        no_coll = {'ms_per_step': e2 / a.steps * 1e3, 'value': world * B * N * R / (e2 / a.steps)}
 
     ms_per_step = elapsed / a.steps * 1e3
     warped = world * B * N * R           # warped events per step, all ranks
@@ -169,18 +223,24 @@ def main():
 
     out = None
     if rank == 0:
-        splat_ms = stage_acc.get('splat', 0.0) / a.steps
-        splat_bytes = B * splat_algorithmic_bytes(N, R, H, W)
-        achieved = splat_bytes / (splat_ms * 1e-3) / 1e9 if splat_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         wl = f'{B}x[{H}x{W} N={N} R={R} theta={a.theta}]'
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(wl, {}).get('k_splat_hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        traffic = load_traffic(wl)
+        ev_bytes = B * event_kernel_algorithmic_bytes(N, R, H, W)
+        kern = {'k_splat': kernel_roofline('k_splat', stage_acc.get('splat', 0.0) / a.steps, ev_bytes, traffic.get('k_splat_hbm_bytes_per_launch')),
+                'k_gather': kernel_roofline('k_gather', stage_acc.get('gather', 0.0) / a.steps, ev_bytes, traffic.get('k_gather_hbm_bytes_per_launch'))}
+        dominant = max(kern.values(), key=lambda d: d['avg_launch_ms'])      # the longest kernel of the step
         eval_bytes = B * algorithmic_bytes(N, R, H, W, dense)
+        roof = dict(dominant)
+        roof.update({'bound': 'hbm',
+                     'bound_note': 'priced against HBM as the contract asks; the kernels are NOT HBM-bound at these sizes: PMC shows the VALU '
+                                   'pipe ~90-100 % busy in both event kernels and k_splat at ~92 % of the measured ds_add_u32 rate '
+                                   f'(profiles/{ROUND}/, DESIGN.md section 6)',
+                     'event_kernels': kern,
+                     'lds_atomic_lane_ops_per_clk_per_cu': (9.0 * B * N * R / (kern['k_splat']['avg_launch_ms'] * 1e-3) / 256 / 2.4e9)
+                     if kern['k_splat']['avg_launch_ms'] > 0 else 0.0,
+                     'lds_atomic_peak_lane_ops_per_clk_per_cu': [4.8, 7.4],
+                     'lds_atomic_note': '9 ds_add_u32 per warped event; peak = tools/lds_atomic_bench.hip (clustered, distinct addresses), '
+                                        'profiles/r01/lds_atomic_microbench.txt'})
         out = {
             'metric': 'warped-events/sec/GPU + loss+grad eval ms, 1e6 events @ 346x260',
             'value': value, 'unit': 'warped-events/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -188,14 +248,10 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'C4 share per GPU: {wl}, EINCM contrast+edge-correlation loss+grad, alpha=20 beta=35',
                        'windows_per_gpu': B, 'events_per_window': N, 'n_refs': R, 'sensor': [H, W],
-                       'theta': [h, w, 2], 'parallelism': f'window-parallel x{world}, no data-path collective'},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_splat', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': splat_bytes, 'avg_launch_ms': splat_ms,
-                         'binding_resource': 'valu issue (PMC: VALU pipe ~85 % busy, profiles/r01/pmc_valu_counter_collection.csv), then lds_atomic',
-                         'lds_atomic_lane_ops_per_clk_per_cu': (9.0 * B * N * R / (splat_ms * 1e-3) / 256 / 2.4e9) if splat_ms > 0 else 0.0,
-                         'lds_atomic_peak_lane_ops_per_clk_per_cu': [4.8, 7.4],
-                         'lds_atomic_note': '9 ds_add_u32 per warped event; peak = tools/lds_atomic_bench.hip (clustered, distinct addresses), profiles/r01/lds_atomic_microbench.txt'},
+                       'theta': [h, w, 2],
+                       'parallelism': f'window-parallel x{world}' + (', async RCCL all-reduce of the scalar batch loss per step' if world > 1
+                                                                    else ', single GPU (no collective)')},
+            'roofline': roof,
             'eval_roofline': {'achieved': eval_bytes / (ms_per_step * 1e-3) / 1e9, 'unit': 'GB/s',
                               'frac': eval_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                               'algorithmic_bytes_per_step': eval_bytes},
@@ -204,8 +260,11 @@ def main():
             'stage_ms_note': 'separate diagnostic pass with every kernel bracketed by HIP events (slower than the timed region)',
             'set_windows_s': t_stage,
             'warped_events_per_s_per_gpu': value / world,
-            'batch_loss_all_ranks': batch_loss_all_ranks,
+            'batch_loss_all_ranks': batch_loss_all,
+            'deterministic': 'integer cross-workgroup accumulation; repeated evaluations are bit-identical (tests/test_gpu_determinism.py)',
         }
+        if no_coll is not None:
+            out['no_collective'] = no_coll
     eng.close()
 
     # ---- single-window latency (second half of the metric: loss+grad eval ms at 1e6 events) ----
@@ -260,37 +319,194 @@ def main():
                                       'note': 'same 8 windows, 4 engine contexts each driven by its own host thread without a '
                                               'join between steps; supplementary, not the headline'}
 
-    # ---- CPU baseline: ports of the reference arithmetic (the reference itself, JAX, cannot run here or on the GPU box) ----
-    # Reported: the C / OpenMP port (oracle/eincm_ref.c) on the host cores of this box; the single-core numpy oracle beside it.
+    # ---- CPU baselines: ports of the reference arithmetic (the reference itself, JAX, cannot run here or on the GPU box) ----
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        from oracle import eincm_oracle as O
-        from oracle import eincm_c_port as CP
-        wn = wins[0]
-        cargs = (wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts'])
-        cores = max(1, min(16, os.cpu_count() or 1, CP.max_threads()))      # a 1-GPU box's CPU share is 16 threads
-        CP.loss_and_grad(theta_at(0)[0], *cargs, alpha, beta, (H, W), nthreads=cores)      # warm (page-in, thread pool)
-        n_eval, t_cpu = 0, 0.0
-        while t_cpu < 8.0 and n_eval < 64:
-            t0 = time.perf_counter()
-            CP.loss_and_grad(theta_at(n_eval)[0], *cargs, alpha, beta, (H, W), nthreads=cores)
-            t_cpu += time.perf_counter() - t0
-            n_eval += 1
-        n_np, t_np = 0, 0.0
-        while t_np < 4.0 and n_np < 4:
-            t0 = time.perf_counter()
-            O.loss_and_grad(theta_at(n_np)[0], *cargs, alpha, beta, 0.0, 0.0, 4 if not dense else 0, 5, (H, W))
-            t_np += time.perf_counter() - t0
-            n_np += 1
-        out['cpu_baseline'] = {'value': n_eval * N * R / t_cpu, 'unit': 'warped-events/s', 'cores': cores, 'kind': 'port',
-                               'sample': f'{n_eval} loss+grad evaluations of 1 window ({H}x{W}, N={N}, R={R}) by the C/OpenMP fp64 port '
-                                         f'(oracle/eincm_ref.c, {cores} threads), {t_cpu:.1f} s; numpy oracle on 1 core: {n_np} evaluations, {t_np:.1f} s',
-                               'eval_ms': t_cpu / n_eval * 1e3, 'numpy_1core_value': n_np * N * R / t_np,
-                               'numpy_1core_eval_ms': t_np / n_np * 1e3, 'host_cores_available': os.cpu_count()}
+        out['cpu_baseline'] = cpu_baseline(wins[0], theta_at, alpha, beta, (H, W), N, R, dense)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline(wn, theta_at, alpha, beta, sensor, N, R, dense):
+    """CPU-C = the C / OpenMP fp64 port (oracle/eincm_ref.c) on 16 threads (the box's nominal CPU share) and
+    on every host core; CPU-B = the torch-CPU fp64 restatement differentiated by autograd on all cores; CPU-A = the numpy oracle on
+    one core.  Bounded samples (about 20 s in all)."""
+    import torch
+    from oracle import eincm_oracle as O
+    from oracle import eincm_c_port as CP
+    from oracle import eincm_torch as OT
+    H, W = sensor
+    cargs = (wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts'])
+    ncpu = os.cpu_count() or 1
+
+    def time_c(threads, budget):
+        CP.loss_and_grad(theta_at(0)[0], *cargs, alpha, beta, (H, W), nthreads=threads)      # warm (page-in, thread pool)
+        n, t = 0, 0.0
+        while t < budget and n < 64:
+            t0 = time.perf_counter()
+            CP.loss_and_grad(theta_at(n)[0], *cargs, alpha, beta, (H, W), nthreads=threads)
+            t += time.perf_counter() - t0
+            n += 1
+        return n, t
+
+    cores = min(ncpu, 16)
+    n_eval, t_cpu = time_c(cores, 6.0)
+    res = {'value': n_eval * N * R / t_cpu, 'unit': 'warped-events/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{n_eval} loss+grad evaluations of 1 window ({H}x{W}, N={N}, R={R}) by the C/OpenMP fp64 port '
+                     f'(oracle/eincm_ref.c, {cores} threads), {t_cpu:.1f} s',
+           'eval_ms': t_cpu / n_eval * 1e3, 'host_cores_available': ncpu}
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = ncpu
+    if usable > cores:                  # every logical CPU this process may run on (a 1-GPU box: 256 logical CPUs, CPU quota of 16)
+        t0 = time.perf_counter()
+        CP.loss_and_grad(theta_at(1)[0], *cargs, alpha, beta, (H, W), nthreads=usable)
+        t_all = time.perf_counter() - t0
+        res['all_cores'] = {'value': N * R / t_all, 'cores': usable, 'eval_ms': t_all * 1e3,
+                            'sample': f'1 evaluation, {t_all:.1f} s, the same port with one thread per logical CPU (beyond the process\'s CPU '
+                                      'quota the threads only contend)'}
+    try:                                # CPU-B: torch fp64 forward + autograd, all cores
+        torch.set_num_threads(ncpu)
+        lvl = 4 if not dense else 0
+        n_t, t_t = 0, 0.0
+        while t_t < 5.0 and n_t < 3:
+            t0 = time.perf_counter()
+            th = theta_at(n_t)[0]
+            OT.loss_and_grad(th, *cargs, alpha, beta, 0.0, 0.0, lvl, (H, W), O.resample_matrix(th.shape[0], H, H / th.shape[0], 'bilinear'),
+                             O.resample_matrix(th.shape[1], W, W / th.shape[1], 'bilinear'))
+            t_t += time.perf_counter() - t0
+            n_t += 1
+        res['torch_cpu'] = {'value': n_t * N * R / t_t, 'cores': ncpu, 'eval_ms': t_t / n_t * 1e3,
+                            'sample': f'{n_t} evaluations, {t_t:.1f} s, torch {torch.__version__} fp64 forward + autograd (oracle/eincm_torch.py)'}
+    except Exception as exc:            # a baseline must not take the bench line down
+        res['torch_cpu'] = {'error': repr(exc)[:200]}
+    n_np, t_np = 0, 0.0
+    while t_np < 3.0 and n_np < 3:
+        t0 = time.perf_counter()
+        O.loss_and_grad(theta_at(n_np)[0], *cargs, alpha, beta, 0.0, 0.0, 4 if not dense else 0, 5, (H, W))
+        t_np += time.perf_counter() - t0
+        n_np += 1
+    res['numpy_1core'] = {'value': n_np * N * R / t_np, 'cores': 1, 'eval_ms': t_np / n_np * 1e3,
+                          'sample': f'{n_np} evaluations, {t_np:.1f} s, oracle/eincm_oracle.py'}
+    return res
+
+
+# =====================================================================================================================
+# mode: one window, events sharded over the ranks (C5)
+# =====================================================================================================================
+def bench_event_sharded(a):
+    import torch
+    import torch.distributed as dist
+    rank, world, dev_index, dev, red_dev, backend = init_dist(a)
+    synth = importlib.import_module('edge-informed-contrast-maximization_amd.synth')
+    engine = importlib.import_module('edge-informed-contrast-maximization_amd.engine')
+    sharding = importlib.import_module('edge-informed-contrast-maximization_amd.sharding')
+
+    H, W = (int(v) for v in a.sensor.split('x'))
+    N, R = a.events, a.refs
+    alpha, beta, gamma = 2000.0, 4000.0, 0.0          # run.sh:104-108 (DSEC weights)
+    win = synth.make_window(7, (H, W), N, R, flow='smooth', flow_mag=20.0)          # the same window on every rank
+    mine = sharding.shard_events(N, rank, world)
+    sl = slice(mine.start, mine.stop)
+    levels = [(1, 1), (2, 2), (4, 4), (8, 8), (16, 16)]
+    thetas = [synth.theta_near_truth(7, win, hw) for hw in levels]
+    eng = engine.Engine((H, W), len(range(*sl.indices(N))), max_refs=R, max_windows=1, device=dev_index)
+    se = sharding.ShardedEngine(eng)
+    t0 = time.perf_counter()
+    se.set_windows([(win['xs'][sl], win['ys'][sl], win['ts'][sl], win['edges'], win['edge_ts'])])
+    t_stage = time.perf_counter() - t0
+
+    def step(k):
+        lv = k % len(levels)
+        p = engine.make_params(alpha, beta, gamma, 0.0, len(levels) - 1 - lv)
+        return se.loss_grad(thetas[lv] * (1.0 + 0.01 * ((k % 7) - 3)), p)
+
+    t_spin = time.perf_counter() + 0.3
+    k = 0
+    while time.perf_counter() < t_spin:
+        step(k); k += 1
+    for k in range(a.warmup):
+        step(k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        v, g = step(a.warmup + k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert np.all(np.isfinite(v)) and np.all(np.isfinite(g))
+
+    # ---- end to end: BFGS over the pyramid on the sharded objective (every rank runs the same SciPy iterations on identical numbers) ----
+    solve = None
+    if a.solve_iters > 0:
+        import scipy.optimize as spo
+        iters = [max(1, round(a.solve_iters * f)) for f in (0.10, 0.14, 0.20, 0.26, 0.30)]      # growing with the level, summing to ~solve_iters
+        theta = np.zeros((1, 1, 2))
+        n_eval = 0
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for li, hw in enumerate(levels):
+            if li:
+                theta = np.repeat(np.repeat(theta, 2, axis=0), 2, axis=1)              # solver.py:350-352 'repeat' upscaling
+            p = engine.make_params(alpha, beta, gamma, 0.0, len(levels) - 1 - li)
+
+            def f(x, _p=p, _s=theta.shape):
+                nonlocal n_eval
+                vv, gg = se.loss_grad(x.reshape(_s), _p)
+                n_eval += 1
+                return float(vv[0]), gg[0].reshape(-1)
+            r = spo.minimize(f, theta.reshape(-1), jac=True, method='BFGS', options={'maxiter': iters[li], 'gtol': 1e-7})
+            theta = r.x.reshape(theta.shape)
+        if world > 1:
+            dist.barrier()
+        solve = {'seconds': time.perf_counter() - t0, 'bfgs_iterations': int(sum(iters)), 'loss_grad_evaluations': n_eval,
+                 'final_loss': float(r.fun)}
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        value = N * R / (elapsed / a.steps)
+        iwe_bytes = R * H * W * 8
+        out = {
+            'metric': 'warped-events/sec/GPU + loss+grad eval ms, 1e6 events @ 346x260',
+            'value': value, 'unit': 'warped-events/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'C5: 1x[{H}x{W} N={N} R={R}] theta pyramid 1..16, events sharded over {world} rank(s), '
+                                   'EINCM loss+grad, alpha=2000 beta=4000',
+                       'events_per_window': N, 'n_refs': R, 'sensor': [H, W], 'theta_levels': levels,
+                       'parallelism': f'event-sharded x{world}: all-reduce(sum) of the int64 IWE accumulator + of the gradient per evaluation',
+                       'backend': backend},
+            'allreduce_bytes_per_evaluation': {'iwe_accumulator_int64': iwe_bytes, 'gradient_fp64_max': 16 * 16 * 2 * 8},
+            'set_windows_s': t_stage,
+            'solve_50_iters_s' if a.solve_iters == 50 else 'solve_s': solve,
+            'roofline': None,
+            'note': 'hardware scaling of this mode is unmeasured until an N > 1 run on a multi-GPU node exists; with EINCM_BENCH_BACKEND=gloo '
+                    'the collective bounces through host memory (1-GPU rehearsal only)',
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    a = parse_args()
+    if a.mode == 'event-sharded':
+        bench_event_sharded(a)
+    else:
+        bench_windows(a)
 
 
 if __name__ == '__main__':

@@ -85,7 +85,6 @@ SIGNATURES = [
     ('eincm_finish_loss_grad', C.c_int, [_P, _D, _D, C.POINTER(Aux)]),
     ('eincm_finish_constants', C.c_int, [_P]),
     ('eincm_iwe_device_ptr', C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
-    ('eincm_set_iwe_scale_events', C.c_int, [_P, C.c_int64]),
     ('eincm_mask_device_ptr', C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     ('eincm_inv_dist_transform', C.c_int, [_P, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_double, _D,
                                            C.POINTER(C.c_int32)]),

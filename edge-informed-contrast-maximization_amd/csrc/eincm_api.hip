@@ -57,10 +57,13 @@ struct eincm_ctx {
     double* d_t = nullptr;         // (maxN)
     Item* d_items = nullptr;       // (max_items) segments walked by k_gather / k_count / k_mask
     Item* d_items_s = nullptr;     // (max_items) shorter segments walked by k_splat
+    Window* d_wins = nullptr;      // (max_items, maxR) destination windows of the gather segments under the current theta
+    Window* d_wins_s = nullptr;    // (max_items, maxR) ... of the splat segments
     int n_items_s = 0; int seg_s = 0; int seg_s_used = 0;
     int wincap = WIN_CAP_DEFAULT;
     bool wincap_fixed = false;     // EINCM_WINCAP pins the capacity; otherwise it is chosen per evaluation from max|theta|
-    bool fused11 = true;           // 2-DoF theta: k_gather11 (all reference times of a segment in one workgroup); EINCM_GATHER11=0: k_gather
+    bool fused11 = false;          // 2-DoF theta: k_gather11 (all reference times of a segment in one workgroup), EINCM_GATHER11=1; default k_gather
+    bool chunk_fixed = false;      // EINCM_CHUNK given
     int g11_per_item = 1;          // slots per segment in d_g11 written by the last gather launch
     // device-side staging (eincm_binning.hip.h)
     int16_t* d_raw_x = nullptr; int16_t* d_raw_y = nullptr; double* d_raw_t = nullptr;   // (maxN) events as handed over
@@ -72,7 +75,7 @@ struct eincm_ctx {
     int64_t max_items = 0;
     float* d_edges = nullptr;      // (B,R,H,W)
     double* d_edge_ts = nullptr;   // (B,R)
-    uint32_t* d_acc = nullptr;     // (B,R,H,W) u32 fixed-point accumulator of the IWE stack; zero between evaluations (consumer-clears)
+    unsigned long long* d_acc = nullptr;   // (B,R,H,W) u64 fixed-point accumulator of the IWE stack (2^30); zero between evaluations (consumer-clears)
     float* d_iwe = nullptr;        // (B,R,H,W) the fp32 IWE stack, written by the statistics pass from d_acc
     float* d_G = nullptr;          // (B,R,H,W)
     float* d_zero_iwe = nullptr;   // (B,H,W)
@@ -82,7 +85,8 @@ struct eincm_ctx {
     double* d_g11 = nullptr;       // (max_items, R, 2) 2-DoF theta: per-workgroup partials of dL/dtheta (k_gather -> k_final)
     int32_t* d_win_item0 = nullptr;// (B) first segment of each window in d_items
     double* d_dtmax = nullptr;     // (B) staging scratch: max |t - tau| per window
-    unsigned* d_gmax = nullptr;    // (B,R) max |dL/dIWE| as float bits (scale of the i64 gradient accumulators)
+    unsigned* d_gmax = nullptr;    // (B,R,ntiles) per-tile max |dL/dIWE| as float bits (scale of the i64 gradient accumulators)
+    unsigned* d_cntmax = nullptr;  // (B) staging scratch: most events on one source pixel
     double* d_tvg = nullptr;       // (B,H,W,2)
     uint8_t* d_mask = nullptr;     // (B,H,W)
     double* d_tmm = nullptr;       // (B,ntiles,4)
@@ -129,7 +133,6 @@ struct eincm_ctx {
     bool acc_dirty = false;        // a forward half was launched and its consumers were not: accumulators must be memset before reuse
     bool Theta_valid = false;      // d_Theta holds the upsampled theta of the last evaluation (2-DoF evaluations skip the image)
     std::vector<double> last_theta11;   // (B,2) theta of the last 2-DoF evaluation (to build d_Theta on demand)
-    int64_t scale_events = 0;      // eincm_set_iwe_scale_events: events per window the u32 accumulator scale must hold (0: the window's own)
 };
 
 namespace {
@@ -215,9 +218,9 @@ void multi_ref_weights(int R, double* w) {
 
 void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_items_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
+    F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_items_s); F(c->d_wins); F(c->d_wins_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
     F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_acc); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
-    F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax);
+    F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax); F(c->d_cntmax);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
     F(c->d_divparts); F(c->d_g2parts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
     F(c->d_rowtap); F(c->d_coltap);
@@ -234,7 +237,8 @@ void free_all(eincm_ctx* c) {
 struct StageTimer {
     eincm_ctx* c; int stage; bool on;
     StageTimer(eincm_ctx* c_, int s) : c(c_), stage(s),
-        on((c_->cflags & EINCM_CF_TIMING) != 0 || ((c_->cflags & EINCM_CF_TIMING_DOMINANT) != 0 && s == EINCM_STAGE_SPLAT)) {
+        on((c_->cflags & EINCM_CF_TIMING) != 0 ||
+           ((c_->cflags & EINCM_CF_TIMING_DOMINANT) != 0 && (s == EINCM_STAGE_SPLAT || s == EINCM_STAGE_GATHER))) {
         if (on) { (void)hipEventRecord(c->ev[stage][0], c->stream); }
     }
     ~StageTimer() {
@@ -290,7 +294,7 @@ unsigned splat_grid(const eincm_ctx* c) { return (unsigned)(((c->n_items_s + NXC
 // consumer clears it.  If a forward half was launched and never consumed (error between the two halves), clear them here.
 int clear_accumulators(eincm_ctx* c) {
     const size_t img = (size_t)c->H * c->W;
-    HIPCHK(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->maxB * c->maxR * img * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_acc, 0, (size_t)c->maxB * c->maxR * img * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_gTheta, 0, (size_t)c->maxB * img * 2 * sizeof(long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_gth, 0, (size_t)2 * c->maxB * c->coarse_cap * sizeof(long long), c->stream));
     c->acc_dirty = false;
@@ -327,14 +331,19 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
     }
     {
         StageTimer t(c, EINCM_STAGE_THETA);
+        const int nwin_threads = (c->n_items + c->n_items_s) * g.R;
         if (const_theta) {
             c->last_theta11.assign(theta_host, theta_host + (size_t)g.B * 2);
             c->Theta_valid = false;
             if (need_theta_image) launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev);
-            else hipLaunchKernelGGL(k_theta_const, dim3((g.B * g.ntiles + NT - 1) / NT), dim3(NT), 0, c->stream, g, use_arg ? 1 : 0, targ,
-                                    theta_dev, c->d_tmm);
+            hipLaunchKernelGGL(k_theta_const, dim3((std::max(g.B * g.ntiles, nwin_threads) + NT - 1) / NT), dim3(NT), 0, c->stream, g,
+                               use_arg ? 1 : 0, targ, theta_dev, c->d_tmm, c->d_edge_ts, c->n_items, c->d_items, c->d_wins,
+                               c->n_items_s, c->d_items_s, c->d_wins_s);
         } else {
             launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev);
+            if (nwin_threads > 0)
+                hipLaunchKernelGGL(k_windows, dim3((nwin_threads + NT - 1) / NT), dim3(NT), 0, c->stream, g, c->d_tmm, c->d_edge_ts,
+                                   c->n_items, c->d_items, c->d_wins, c->n_items_s, c->d_items_s, c->d_wins_s);
         }
     }
     {
@@ -346,7 +355,7 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
             const size_t lds_bytes = (size_t)(lds_multi ? 2 : 1) * g.wincap * sizeof(float)
                                    + (theta_mode == THETA_TILE ? TS * TS * sizeof(double2) : 0);
 #define SPLAT_ARGS dim3(splat_grid(c)), dim3(NT), lds_bytes, c->stream, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
-                   c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wc, c->d_acc
+                   c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wins_s, c->d_acc
             if (lds_multi)                      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<0, 1>), SPLAT_ARGS);      // long segments (EINCM_SEG_SPLAT > EINCM_CHUNK)
             else if (theta_mode == THETA_CONST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_CONST, 0>), SPLAT_ARGS);
             else                                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_TILE, 0>), SPLAT_ARGS);
@@ -469,13 +478,13 @@ int eval_end_launch(eincm_ctx* c) {
         // accumulator zero again.
         if (g2_from_imgrad && g.ntiles >= NSPART) {
             g.nparts = NSPART;
-            hipLaunchKernelGGL(k_stats_stream, dim3(NSPART, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_acc, c->d_iwe, c->d_edges, c->d_wc,
-                               c->d_parts, c->d_gmax);
+            hipLaunchKernelGGL(k_stats_stream, dim3(NSPART, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_acc, c->d_iwe, c->d_edges,
+                               c->d_parts);
         } else {
             g.nparts = g.ntiles;
             const size_t ntot = (size_t)g.B * g.R * g.H * g.W;
             hipLaunchKernelGGL(k_iwe_finish, dim3((unsigned)std::min<size_t>((ntot + NT - 1) / NT, 2048)), dim3(NT), 0, c->stream, g,
-                               c->d_acc, c->d_iwe, c->d_wc, c->d_gmax);
+                               c->d_acc, c->d_iwe);
             hipLaunchKernelGGL(k_stats, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_edges, c->d_parts,
                                g2_from_imgrad ? 0 : 1);
         }
@@ -491,13 +500,16 @@ int eval_end_launch(eincm_ctx* c) {
                            c->d_tvparts, full_aux ? 1 : 0);
     }
     const bool direct11 = want_grad && !identity && h == 1 && w == 1;
+    // a window with a handful of events: 61-bit fixed point in the per-pixel gradient sums (grad_shift_pixel); speed is irrelevant there
+    bool wide = false;
+    for (int b = 0; b < g.B; ++b) wide = wide || (c->win_events[b] * (int64_t)g.R < 4096);
     if (want_grad) {
         {
             StageTimer t(c, EINCM_STAGE_IMGRAD);
             if (div_grad)
                 hipLaunchKernelGGL(k_divgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_parts,
                                    c->d_gdiv, c->d_dgparts);
-            hipLaunchKernelGGL(k_imgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, ep, c->d_iwe, c->d_edges,
+            hipLaunchKernelGGL(k_imgrad, dim3((g.ntiles + IMG_TPG - 1) / IMG_TPG, g.R, g.B), dim3(NT), 0, c->stream, g, ep, c->d_iwe, c->d_edges,
                                c->d_parts, c->d_wc, c->d_gdiv, c->d_dgparts, c->d_g2parts, c->d_G, c->d_gmax);
         }
         {
@@ -505,7 +517,7 @@ int eval_end_launch(eincm_ctx* c) {
             if (c->n_items > 0) {
 #define GATHER_ARGS dim3(event_grid(c)), dim3(NT), \
                     g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), c->stream, \
-                    g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_gTheta, \
+                    g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_wins, c->d_gTheta, \
                     direct11 ? 1 : 0, c->d_g11, c->d_wc, c->d_gmax, direct11 ? THETA_CONST : THETA_TILE
                 if (direct11 && c->fused11) {
                     // all reference times of a segment in one workgroup: RF windows of `cap` floats in LDS (cap chosen so that they fit)
@@ -525,10 +537,12 @@ int eval_end_launch(eincm_ctx* c) {
 #undef G11_ARGS
                     c->g11_per_item = nrg;
                 } else if (direct11) {
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_CONST>), GATHER_ARGS);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_CONST, 0>), GATHER_ARGS);
                     c->g11_per_item = g.R;
+                } else if (wide) {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_TILE, 1>), GATHER_ARGS);
                 } else {
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_TILE>), GATHER_ARGS);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_TILE, 0>), GATHER_ARGS);
                 }
 #undef GATHER_ARGS
             }
@@ -539,8 +553,8 @@ int eval_end_launch(eincm_ctx* c) {
         if (!identity && nsrc > 0) {
             StageTimer t(c, EINCM_STAGE_PROJECT);
             hipLaunchKernelGGL(k_project, dim3(g.ntiles, g.B, nsrc), dim3(NT), 0, c->stream, g, h, w,
-                               (int)c->coarse_cap, direct11 ? 1 : 0, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_gTheta, c->d_tvg, c->d_gth,
-                               c->d_gth + (size_t)c->maxB * c->coarse_cap);
+                               (int)c->coarse_cap, direct11 ? 1 : 0, wide ? 1 : 0, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_gTheta, c->d_tvg,
+                               c->d_wc, c->d_gmax, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap);
         }
     }
     {
@@ -551,7 +565,7 @@ int eval_end_launch(eincm_ctx* c) {
                            c->d_g11, c->d_win_item0, c->n_items, c->g11_per_item, c->d_gmax,
                            zero_copy_out ? c->h_outs : c->d_outs, zero_copy_out ? c->h_grad : c->d_grad, want_grad ? 1 : 0);
         if (want_grad && identity) {
-            hipLaunchKernelGGL(k_final_dense, dim3(256, g.B), dim3(NT), 0, c->stream, g, ep.use_tv_grad, c->d_gTheta,
+            hipLaunchKernelGGL(k_final_dense, dim3(256, g.B), dim3(NT), 0, c->stream, g, ep.use_tv_grad, wide ? 1 : 0, c->d_gTheta,
                                c->d_tvg, c->d_wc, c->d_gmax, c->d_outs, c->d_grad);
         }
     }
@@ -713,7 +727,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     eincm_ctx* c = new eincm_ctx();
     c->device = device; c->H = H; c->W = W; c->maxR = max_refs; c->maxB = max_windows; c->maxN = max_events_total;
     c->cflags = flags;
-    if (const char* s = getenv("EINCM_CHUNK")) { int v = atoi(s); if (v >= NT && v <= MAX_CHUNK) c->chunk = (v / NT) * NT; }
+    if (const char* s = getenv("EINCM_CHUNK")) { int v = atoi(s); if (v >= NT && v <= MAX_CHUNK) { c->chunk = (v / NT) * NT; c->chunk_fixed = true; } }
     if (const char* s = getenv("EINCM_SEG")) { int v = atoi(s); if (v >= 64 && v <= MAX_SEG) c->seg = v; }
     if (const char* s = getenv("EINCM_GATHER11")) c->fused11 = atoi(s) != 0;
     if (const char* s = getenv("EINCM_SEG_SPLAT")) { int v = atoi(s); if (v >= 64 && v <= MAX_SEG) c->seg_s = v; }
@@ -736,6 +750,8 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_t, (size_t)max_events_total));
     TRY(dalloc(&c->d_items, (size_t)c->max_items));
     TRY(dalloc(&c->d_items_s, (size_t)c->max_items));
+    TRY(dalloc(&c->d_wins, (size_t)c->max_items * max_refs));
+    TRY(dalloc(&c->d_wins_s, (size_t)c->max_items * max_refs));
     c->host_binning = (ntiles > BIN_MAX_TILES) || (getenv("EINCM_HOST_BINNING") != nullptr);
     if (!c->host_binning) {
         c->max_binblocks = max_events_total / BIN_CHUNK + (int64_t)B + 1;
@@ -755,14 +771,15 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_edges, B * R * img));
     TRY(dalloc(&c->d_edge_ts, B * R));
     TRY(dalloc(&c->d_acc, B * R * img));
-    TRY(hipMemset(c->d_acc, 0, B * R * img * sizeof(uint32_t)));
+    TRY(hipMemset(c->d_acc, 0, B * R * img * sizeof(unsigned long long)));
     TRY(dalloc(&c->d_iwe, B * R * img));
     TRY(dalloc(&c->d_G, B * R * img));
     TRY(dalloc(&c->d_g11, (size_t)(c->max_items + NXCD) * R * 2));
     TRY(dalloc(&c->d_win_item0, B + 1));
     TRY(dalloc(&c->d_dtmax, B));
-    TRY(dalloc(&c->d_gmax, B * R));
-    TRY(hipMemset(c->d_gmax, 0, B * R * sizeof(unsigned)));
+    TRY(dalloc(&c->d_cntmax, B));
+    TRY(dalloc(&c->d_gmax, B * R * ntiles));
+    TRY(hipMemset(c->d_gmax, 0, B * R * ntiles * sizeof(unsigned)));
     TRY(dalloc(&c->d_zero_iwe, B * img));
     TRY(dalloc(&c->d_Theta, B * img * 2));
     TRY(dalloc(&c->d_theta_in, B * img * 2));
@@ -840,8 +857,13 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     // more numerous segments finish sooner: 100.9 -> 97.4 us for one 10^6-event window, while the 8-window batch prefers 8192
     if (c->seg <= 0 && ((double)N / 8192.0 + 0.5 * n_windows * g.ntiles) * n_refs < 2048.0) seg = 4096;
     c->seg_used = seg;
+    // k_splat: 4096-event segments unless the batch is large enough to fill the chip twice over with 8192-event ones; the longer
+    // segments halve the number of window flushes (u64 atomics), which is what the exact accumulator costs: measured 115 -> 112 us
+    // on the 8-window batch, while a single 10^6-event window is faster with 4096 (more workgroups than slots matters more there)
     int seg_s = c->seg_s > 0 ? c->seg_s : 4096;
+    if (c->seg_s <= 0 && ((double)N / 8192.0 + 0.5 * n_windows * g.ntiles) * n_refs >= 4096.0) seg_s = 8192;
     c->seg_s_used = seg_s;
+    if (!c->chunk_fixed) c->chunk = std::max(4096, std::min(seg_s, MAX_CHUNK));     // single-chunk segments: no f32 commit pass
     const size_t img = (size_t)H * W;
     for (int b = 0; b < n_windows; ++b) {
         memset(&c->h_wc[b], 0, sizeof(WinConst));
@@ -850,6 +872,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             if (!std::isfinite(edge_ts[b * n_refs + r])) return fail(c, EINCM_ERR_ARG, "edge_ts[%d,%d] is not finite", b, r);
     }
     int n_items_total = 0, n_items_s_total = 0;
+    std::vector<unsigned> cntmax_h((size_t)n_windows, 0u);
     std::vector<double> dtmax_h((size_t)n_windows, 0.0);
     std::vector<int32_t> item0_h;                  // host path only
     if (!c->host_binning) {
@@ -958,6 +981,10 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             if (!std::isfinite(t[i])) return fail(c, EINCM_ERR_ARG, "event %lld of window %d has a non-finite timestamp", (long long)i, b);
             ++cnt[(size_t)(y[i] / TS) * g.tilesX + (x[i] / TS) + 1];
         }
+        {   // most events on one source pixel
+            std::vector<uint32_t> pc((size_t)H * W, 0u);
+            for (int64_t i = 0; i < n; ++i) cntmax_h[b] = std::max(cntmax_h[b], ++pc[(size_t)y[i] * W + x[i]]);
+        }
         for (int k = 0; k < g.ntiles; ++k) cnt[k + 1] += cnt[k];
         std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
         for (int64_t i = 0; i < n; ++i) {
@@ -1016,7 +1043,14 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->g = g; c->n_items = n_items_total; c->n_items_s = n_items_s_total; c->n_events = N;
     c->win_events.assign(n_events, n_events + n_windows);
-    if (c->n_items > 0) {
+    if (c->n_items > 0 && !c->host_binning) {     // event mask + most events on one source pixel, per tile from its LDS histogram
+        HIPCHK(c, hipMemsetAsync(c->d_cntmax, 0, (size_t)n_windows * sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL(k_tile_counts, dim3(g.ntiles, n_windows), dim3(NT), 0, c->stream, g, c->d_tilebase, c->d_tilecount, c->d_xy,
+                           c->d_mask, c->d_cntmax);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(cntmax_h.data(), c->d_cntmax, (size_t)n_windows * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else if (c->n_items > 0) {
         hipLaunchKernelGGL(k_mask, dim3(std::min(c->n_items, 2048)), dim3(NT), 0, c->stream, g, c->d_items, c->n_items, c->d_xy, c->d_mask);
         HIPCHK(c, hipGetLastError());
     }
@@ -1027,10 +1061,9 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         WinConst& wc = c->h_wc[b];
         wc.c0_gradmag = 1.0; wc.c0_var = 1.0; wc.d0 = 1.0;
         for (int r = 0; r < n_refs; ++r) wc.zc[r] = 1.0;
-        // scales of the integer accumulators: the u32 IWE stack must hold every event that may land in it (all shards of an
-        // event-sharded window: eincm_set_iwe_scale_events), the i64 gradient sums this context's own events
+        // bounds behind the scale of the i64 gradient accumulators (grad_shift)
         wc.nev = (double)std::max<int64_t>(n_events[b], 1);
-        wc.gshift = iwe_shift((double)std::max<int64_t>(c->scale_events > 0 ? c->scale_events : n_events[b], 1));
+        wc.cntmax = (double)std::max(cntmax_h[b], 1u);
         wc.dtmax = dtmax_h[b];
     }
     HIPCHK(c, hipMemcpyAsync(c->d_wc, c->h_wc, (size_t)n_windows * sizeof(WinConst), hipMemcpyHostToDevice, c->stream));
@@ -1112,12 +1145,6 @@ int eincm_iwe_device_ptr(eincm_ctx* c, void** dptr, int64_t* n_words) {
     return EINCM_OK;
 }
 
-int eincm_set_iwe_scale_events(eincm_ctx* c, int64_t n_events_per_window) {
-    if (!c) return EINCM_ERR_ARG;
-    if (n_events_per_window < 0) return fail(c, EINCM_ERR_ARG, "n_events_per_window negative");
-    c->scale_events = n_events_per_window;
-    return EINCM_OK;
-}
 
 int eincm_mask_device_ptr(eincm_ctx* c, void** dptr, int64_t* n_bytes) {
     if (!c || !dptr || !n_bytes) return EINCM_ERR_ARG;

@@ -16,7 +16,7 @@
 // destinations of an item fall in a small bounding box that lives in LDS (u32 fixed-point ds_add), so HBM sees one
 // coalesced row-wise flush per item instead of 9 scattered atomics per warped event.
 //
-// Every accumulation that crosses workgroups is INTEGER (fixed point): the IWE stack is summed as u32 at a per-window scale
+// Every accumulation that crosses workgroups is INTEGER (fixed point): the IWE stack is summed as u64 at the fixed scale 2^30
 // (k_splat -> acc, converted to the fp32 IWE by the statistics pass), dL/dTheta and dL/dtheta as i64 at a per-window scale derived
 // from max|dL/dIWE| (k_gather / k_project), and the 2-DoF gradient as per-workgroup fp64 partials summed in a fixed order
 // (k_final).  Integer adds commute, so results are bit-identical from run to run whatever order the hardware retires atomics in.
@@ -86,17 +86,16 @@ struct WinConst {                 // theta-independent constants of a window (lo
     double sE[16], sEE[16];       // sum E_r, sum E_r^2
     double mrw[16];               // multi-reference weights (losses.py:39-46)
     double dtmax;                 // max |t_e - tau_r| over the window's events and reference times (bounds a gradient term)
-    double nev;                   // events that may contribute to this window's images (all shards of an event-sharded window)
-    int32_t gshift, _pad;         // the u32 IWE accumulator of this window holds pixel * 2^gshift (iwe_shift)
+    double nev;                   // events staged in this window of this context
+    double cntmax;                // most events on one source pixel (bounds a per-pixel gradient sum)
 };
 
-// Scale of a window's u32 IWE accumulator.  One tap is <= 1/(2 pi) and no event puts two taps on one pixel, so a pixel is at most
-// 0.1592 * nev whatever theta is: 2^k with 0.16 * nev * 2^k <= 2^32 cannot overflow (a window of 10^6 events: k = 14, of 3*10^4: k = 19).
-__host__ __device__ __forceinline__ int iwe_shift(double nev) {
-    int k = 30;
-    while (k > 0 && 0.16 * nev * (double)(1u << k) > 4294967295.0) --k;
-    return k;
-}
+// The IWE accumulator holds pixel * 2^ACC_SHIFT as u64.  A segment's u32 LDS sums have scale 2^fshift with fshift <= 30 = ACC_SHIFT,
+// so the flush is an exact left shift: the accumulated image is the exact sum of the per-tap fixed-point values, whatever the order.
+// One tap is <= 1/(2 pi) and no event puts two taps on one pixel: pixel <= 0.16 * N, and 0.16 * 2e9 events * 2^30 < 2^63 cannot overflow.
+// (A u32 accumulator at a scale safe for the worst case - 2^14 at 10^6 events, 2^11 at 10^7 - was measured first: 2.6e-4 relative
+// error in the gradient at 10^7 events.  u64 atomics cost 0-5 % of k_splat, the flush hides behind the event loop.)
+constexpr int ACC_SHIFT = 30;
 
 // i64 fixed point of the gradient accumulators: value * 2^eg, magnitudes < 2^51 so that (a) the fp64 -> i64 conversion by the
 // 1.5 * 2^52 magic constant is exact rounding and (b) i64 -> fp64 is exact.  bound = an upper bound of the sum of the magnitudes of
@@ -111,13 +110,51 @@ constexpr double FIX64_MAGIC = 6755399441055744.0;               // 1.5 * 2^52: 
 __device__ __forceinline__ long long fix64(double scaled) {      // round-to-nearest-even integer of |scaled| < 2^51
     return __double_as_longlong(scaled + FIX64_MAGIC) - __double_as_longlong(FIX64_MAGIC);
 }
+// The same for |scaled| < 2^62, in two 32-bit halves (gfx950 has no fp64 -> i64 conversion): used where a sum needs every bit it
+// can get and the conversion is per pixel, not per event (k_project).
+__device__ __forceinline__ int fix64_wide_shift(double bound) {
+    if (!(bound > 0.0) || !(bound < 1.0e300)) return 0;
+    int e;
+    (void)frexp(bound, &e);
+    return 61 - e;
+}
+__device__ __forceinline__ long long fix64_wide(double scaled) {
+    const long long hi = fix64(scaled * (1.0 / 4294967296.0));              // |.| < 2^30
+    const double rem = fma(-(double)hi, 4294967296.0, scaled);              // exact, |rem| <= 2^31
+    return hi * 4294967296ll + fix64(rem);
+}
 // |dL/dw| of one event at one reference time is at most max|G| * sum_taps k |q| <= max|G| * 9 * 0.1592 * 1.5 = 2.15 max|G|; times
-// |dt| <= dtmax; summed over nev * R events; times <= 4 for the resampling weights of the projection (sum |A_H||A_W| of any method).
-__device__ __forceinline__ int grad_shift(const WinConst& c, const unsigned* __restrict__ gmax_row, int R) {
+// |dt| <= dtmax.  Two scales, because max|G| sits on the few arg-min / arg-max pixels of the normalisation and is orders of
+// magnitude above a typical |G|, so bits are precious:
+//   per SOURCE PIXEL (LDS accumulators of k_gather, the dL/dTheta image): at most cntmax events per pixel, R reference times; < 2^50
+//     (the cheap per-event conversion fix64);
+//   per theta CELL (k_project's sums): all nev * R events, times <= 4 for the resampling weights (sum |A_H||A_W| of any method);
+//     < 2^61 (fix64_wide): at 10^7 events a 2^50 range left 1e-6 per rounding and 2e-5 relative error in the gradient.
+// Every event is rounded once at the fine pixel scale; a pixel's total is rounded once more when it enters a cell.
+// max |G| of a window = max over the per-tile maxima k_imgrad stored (R * ntiles words; plain stores there, because 4000
+// same-address atomicMax cost k_imgrad 18 us).  Called by every thread of a workgroup; result in all threads.  One __syncthreads.
+__device__ __forceinline__ double gmax_of(const unsigned* __restrict__ gmax_win, int n, unsigned* lds_scratch /* NWAVE words */) {
     unsigned m = 0u;
-    for (int r = 0; r < R; ++r) m = max(m, gmax_row[r]);         // non-negative floats order like their bit patterns
-    const double gm = (double)__uint_as_float(m);
-    return fix64_shift(2.15 * gm * c.dtmax * fmax(c.nev, 1.0) * (double)R * 4.0);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = max(m, gmax_win[i]);       // non-negative floats order like their bit patterns
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) lds_scratch[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const int nw = (blockDim.x + 63) >> 6;
+    m = lds_scratch[0];
+    for (int i = 1; i < nw; ++i) m = max(m, lds_scratch[i]);
+    return (double)__uint_as_float(m);
+}
+// wide: 61 bits and the two-halves conversion per event (10 % of k_gather).  The host asks for it when a window has so few events
+// that speed is irrelevant: with a handful of events the arg-max term of the normalisation can put max|G| fifteen orders of
+// magnitude above the gradient that survives the cancellation (fuzz case: one event, max|G| 8.5e11, max|dL/dtheta| 0.036), and
+// 50 bits under that bound leave 1e-3.
+__device__ __forceinline__ int grad_shift_pixel(const WinConst& c, double gm, int R, bool wide) {
+    const double bound = 2.15 * gm * c.dtmax * fmax(c.cntmax, 1.0) * (double)R;
+    return wide ? fix64_wide_shift(bound) : fix64_shift(bound);
+}
+__device__ __forceinline__ int grad_shift(const WinConst& c, double gm, int R) {
+    return fix64_wide_shift(2.15 * gm * c.dtmax * fmax(c.nev, 1.0) * (double)R * 4.0);
 }
 
 struct EvalParams {
@@ -332,17 +369,53 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
     }
 }
 
+// The destination windows of every (segment, reference time) pair, computed once per evaluation instead of by every thread of
+// every event workgroup (item_window is ~150 instructions, a tenth of a short segment's work).  Thread per (segment, r).
+__device__ __forceinline__ void windows_of(const Geom& g, int idx, int n_a, const Item* __restrict__ items_a, Window* __restrict__ wins_a,
+                                           int n_b, const Item* __restrict__ items_b, Window* __restrict__ wins_b,
+                                           const double* __restrict__ tmm, const double* __restrict__ edge_ts, bool const_theta, const ThetaArg& targ,
+                                           const double* __restrict__ theta, int use_arg) {
+    const bool first = idx < n_a * g.R;
+    const int k = first ? idx : idx - n_a * g.R;
+    if (!first && k >= n_b * g.R) return;
+    const Item it = (first ? items_a : items_b)[k / g.R];
+    const int r = k % g.R;
+    double mm4[4];
+    if (const_theta) {
+        const double vx = use_arg ? targ.v[2 * it.win] : theta[2 * it.win], vy = use_arg ? targ.v[2 * it.win + 1] : theta[2 * it.win + 1];
+        mm4[0] = vx; mm4[1] = vx; mm4[2] = vy; mm4[3] = vy;
+    } else {
+        const double* mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
+        mm4[0] = mm[0]; mm4[1] = mm[1]; mm4[2] = mm[2]; mm4[3] = mm[3];
+    }
+    (first ? wins_a : wins_b)[k] = item_window(g, it, mm4, edge_ts[it.win * g.R + r]);
+}
+
 // 2-DoF theta (1,1,2): Theta is one constant per window, so the velocity bounds of every tile are that constant; no image is
-// written.  grid (ceil(B*ntiles/NT)).  theta rides in the kernel arguments (B*2 <= THETA_ARG_MAX) or is read from `theta`.
+// written.  Also fills the window tables of both segment lists.  grid covers max(B*ntiles, (n_a + n_b) * R) threads.
+// theta rides in the kernel arguments (B*2 <= THETA_ARG_MAX) or is read from `theta`.
 __global__ __launch_bounds__(NT) void k_theta_const(Geom g, int use_arg, ThetaArg targ, const double* __restrict__ theta,
-                                                     double* __restrict__ tmm)
+                                                     double* __restrict__ tmm, const double* __restrict__ edge_ts,
+                                                     int n_a, const Item* __restrict__ items_a, Window* __restrict__ wins_a,
+                                                     int n_b, const Item* __restrict__ items_b, Window* __restrict__ wins_b)
 {
     const int i = blockIdx.x * NT + threadIdx.x;
-    if (i >= g.B * g.ntiles) return;
-    const int b = i / g.ntiles;
-    const double vx = use_arg ? targ.v[2 * b] : theta[2 * b], vy = use_arg ? targ.v[2 * b + 1] : theta[2 * b + 1];
-    double* o = tmm + (size_t)i * 4;
-    o[0] = vx; o[1] = vx; o[2] = vy; o[3] = vy;          // NaN stays NaN: item_window and k_final see it
+    if (i < g.B * g.ntiles) {
+        const int b = i / g.ntiles;
+        const double vx = use_arg ? targ.v[2 * b] : theta[2 * b], vy = use_arg ? targ.v[2 * b + 1] : theta[2 * b + 1];
+        double* o = tmm + (size_t)i * 4;
+        o[0] = vx; o[1] = vx; o[2] = vy; o[3] = vy;          // NaN stays NaN: item_window and k_final see it
+    }
+    windows_of(g, i, n_a, items_a, wins_a, n_b, items_b, wins_b, tmm, edge_ts, true, targ, theta, use_arg);
+}
+
+// Any other theta: the window tables after k_theta has written the per-tile velocity bounds.  grid covers (n_a + n_b) * R threads.
+__global__ __launch_bounds__(NT) void k_windows(Geom g, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
+                                                 int n_a, const Item* __restrict__ items_a, Window* __restrict__ wins_a,
+                                                 int n_b, const Item* __restrict__ items_b, Window* __restrict__ wins_b)
+{
+    ThetaArg none;
+    windows_of(g, blockIdx.x * NT + threadIdx.x, n_a, items_a, wins_a, n_b, items_b, wins_b, tmm, edge_ts, false, none, nullptr, 0);
 }
 
 // Block -> (segment, reference time).  The R blocks that process one segment at the R reference times read the
@@ -369,8 +442,8 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
         const double* __restrict__ Theta,      // (B,H,W,2)
         const double* __restrict__ tmm,        // (B,ntiles,4)
         const double* __restrict__ edge_ts,    // (B,R)
-        const WinConst* __restrict__ wc,       // (B): the window's accumulator scale
-        uint32_t* __restrict__ acc)            // (B,R,H,W) u32 fixed point at 2^gshift, zero on entry (cleared by its consumer)
+        const Window* __restrict__ wins,       // (n_items, R) destination windows of this evaluation (k_theta_const / k_windows)
+        unsigned long long* __restrict__ acc)  // (B,R,H,W) u64 fixed point at 2^ACC_SHIFT, zero on entry (cleared by its consumer)
 {
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsu[];
@@ -392,7 +465,7 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
             thtile[p] = (y < g.H && x < g.W) ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : make_double2(0.0, 0.0);
         }
     }
-    const Window wn = item_window(g, it, tmm + ((size_t)it.win * g.ntiles + it.tile) * 4, tau);
+    const Window wn = wins[(size_t)item * g.R + r];
     const int nwin = wn.ww * wn.wh;
     const bool multi = MULTI != 0 && it.count > chunk;       // MULTI == 0: the commit logic in the loop folds away
     {   // clear the window(s), 16 B per lane
@@ -403,9 +476,7 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     }
     __syncthreads();
 
-    uint32_t* __restrict__ img = acc + ((size_t)it.win * g.R + r) * g.H * g.W;
-    const int gshift = wc[it.win].gshift;
-    const float GSCALE = ldexpf(1.0f, gshift);
+    unsigned long long* __restrict__ img = acc + ((size_t)it.win * g.R + r) * g.H * g.W;
     const uint32_t* __restrict__ exy = ev_xy + it.begin;
     const double* __restrict__ et = ev_t + it.begin;
     const int n = it.count;
@@ -455,8 +526,9 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
                         atomicAdd(ldsu + cy * wn.ww + cx, fix_u32(ky[dy], kx[dx]));
                     } else {
                         const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
-                        // straight to HBM in the accumulator's own scale (ky carries 2^fshift)
-                        if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, fix_u32(ky[dy] * FIX_INV * GSCALE, kx[dx]));
+                        // straight to HBM in the accumulator's own scale (ky carries 2^fshift; a tap * 2^30 fits 32 bits)
+                        if (gx >= 0 && gy >= 0)
+                            atomicAdd(img + (size_t)gy * g.W + gx, (unsigned long long)fix_u32(ky[dy] * FIX_INV * 1073741824.0f, kx[dx]));
                     }
                 }
             }
@@ -489,23 +561,22 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
         if (j + 2 < iters) step(C, A, B, j + 2);
     }
     if (!multi) __syncthreads();
-    // row-wise flush: a wave walks one window row -> contiguous u32 atomics on one image row.  The segment's exact integer sums
-    // (scale 2^fshift) are rounded once to the window's accumulator scale 2^gshift; integer adds commute, so the image does not
-    // depend on the order in which the workgroups arrive.
+    // row-wise flush: a wave walks one window row -> contiguous u64 atomics on one image row.  The segment's exact integer sums
+    // (scale 2^fshift) are shifted to the accumulator's scale 2^ACC_SHIFT without rounding; integer adds commute, so the image
+    // does not depend on the order in which the workgroups arrive.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int down = fshift - gshift;                // > 0: drop bits (round to nearest), <= 0: exact left shift
-    auto to_acc = [&](int i) -> uint32_t {
-        if (multi) return (uint32_t)fmaf(ldsf[i], GSCALE, 0.5f);
-        const uint32_t u = ldsu[i];
-        return down > 0 ? ((u >> down) + ((u >> (down - 1)) & 1u)) : (u << (-down));     // round half up without a carry out of 32 bits
+    const int up = ACC_SHIFT - fshift;               // >= 0 (fix_shift caps at 30)
+    auto to_acc = [&](int i) -> unsigned long long {
+        if (multi) return (unsigned long long)fix64((double)ldsf[i] * 1073741824.0);     // f32 segment sums of the multi-chunk form
+        return (unsigned long long)ldsu[i] << up;
     };
     if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {
         // the usual case, the window lies inside the image: no index rule per pixel
-        uint32_t* __restrict__ dst = img + (size_t)wn.oy * g.W + wn.ox;
+        unsigned long long* __restrict__ dst = img + (size_t)wn.oy * g.W + wn.ox;
         for (int row = wv; row < wn.wh; row += NWAVE) {
             for (int col = lane; col < wn.ww; col += 64) {
-                const uint32_t v = to_acc(row * wn.ww + col);
-                if (v != 0u) atomicAdd(dst + row * g.W + col, v);
+                const unsigned long long v = to_acc(row * wn.ww + col);
+                if (v != 0ull) atomicAdd(dst + row * g.W + col, v);
             }
         }
         return;
@@ -514,8 +585,8 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
         const int gy = wrap_drop(wn.oy + row, g.H);
         if (gy < 0) continue;
         for (int col = lane; col < wn.ww; col += 64) {
-            const uint32_t v = to_acc(row * wn.ww + col);
-            if (v != 0u) {
+            const unsigned long long v = to_acc(row * wn.ww + col);
+            if (v != 0ull) {
                 const int gx = wrap_drop(wn.ox + col, g.W);
                 if (gx >= 0) atomicAdd(img + (size_t)gy * g.W + gx, v);
             }
@@ -608,37 +679,32 @@ __global__ __launch_bounds__(NT) void k_stats(Geom g, const float* __restrict__ 
 
 // k_iwe_finish: the u32 accumulator becomes the fp32 IWE stack, and is cleared for the next evaluation (consumer-clears).
 // Used on the paths whose statistics kernel is the tiled k_stats (forward-only evaluations); gradient evaluations do the same
-// inside k_stats_stream.  grid-stride over (B,R,H,W); also resets the max|dL/dIWE| words.
-__global__ __launch_bounds__(NT) void k_iwe_finish(Geom g, uint32_t* __restrict__ acc, float* __restrict__ iwe,
-                                                    const WinConst* __restrict__ wc, unsigned* __restrict__ gmax)
+// inside k_stats_stream.  grid-stride over (B,R,H,W).
+constexpr double ACC_INV = 1.0 / 1073741824.0;     // 2^-ACC_SHIFT
+__global__ __launch_bounds__(NT) void k_iwe_finish(Geom g, unsigned long long* __restrict__ acc, float* __restrict__ iwe)
 {
-    const size_t per = (size_t)g.R * g.H * g.W, n = per * g.B;
-    if (blockIdx.x == 0)
-        for (int k = threadIdx.x; k < g.B * g.R; k += NT) gmax[k] = 0u;
+    const size_t n = (size_t)g.B * g.R * g.H * g.W;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
-        const uint32_t a = acc[i];
-        iwe[i] = ldexpf((float)a, -wc[i / per].gshift);
-        if (a != 0u) acc[i] = 0u;
+        const unsigned long long a = acc[i];
+        iwe[i] = (float)((double)a * ACC_INV);
+        if (a != 0ull) acc[i] = 0ull;
     }
 }
 
 // k_stats_stream: the same partials as k_stats without the contrast energy, as a pure streaming reduction.  The partials have
 // no per-tile meaning (they are only ever reduced over the whole image), so NSPART fat blocks per image read the image with
 // coalesced grid-stride loads and pay the fp64 cross-lane reduction once each.  grid (NSPART, R, B).
-// It is also the consumer of the u32 accumulator: converts it to the fp32 IWE stack (what every later kernel reads) and clears it.
+// It is also the consumer of the u64 accumulator: converts it to the fp32 IWE stack (what every later kernel reads) and clears it.
 constexpr int NSPART = 32;
-__global__ __launch_bounds__(NT) void k_stats_stream(Geom g, uint32_t* __restrict__ acc, float* __restrict__ iwe,
-                                                      const float* __restrict__ edges, const WinConst* __restrict__ wc,
-                                                      StatPart* __restrict__ parts, unsigned* __restrict__ gmax)
+__global__ __launch_bounds__(NT) void k_stats_stream(Geom g, unsigned long long* __restrict__ acc, float* __restrict__ iwe,
+                                                      const float* __restrict__ edges, StatPart* __restrict__ parts)
 {
     __shared__ double red[NWAVE][8];
     const int part = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
     const size_t n = (size_t)g.H * g.W;
-    uint32_t* __restrict__ A = acc + ((size_t)b * g.R + r) * n;
+    unsigned long long* __restrict__ A = acc + ((size_t)b * g.R + r) * n;
     float* __restrict__ I = iwe + ((size_t)b * g.R + r) * n;
     const float* __restrict__ E = edges + ((size_t)b * g.R + r) * n;
-    const float inv = ldexpf(1.0f, -wc[b].gshift);
-    if (part == 0 && threadIdx.x == 0) gmax[b * g.R + r] = 0u;       // k_imgrad raises it again (atomicMax)
     double mn = INFINITY, mx = -INFINITY, cmn = 0.0, cmx = 0.0, sI = 0.0, sII = 0.0, sEI = 0.0;
     auto take = [&](float fv, float fe) {          // branch-free: (min, #ties) and (max, #ties) are tracked with selects
         const double v = (double)fv, e = (double)fe;
@@ -647,17 +713,17 @@ __global__ __launch_bounds__(NT) void k_stats_stream(Geom g, uint32_t* __restric
         mn = fmin(mn, v); mx = fmax(mx, v);
         sI += v; sII += v * v; sEI += e * v;
     };
-    auto conv = [&](int i, uint32_t a) -> float {  // u32 -> fp32 pixel (rounds to 24 bits), stored for the later kernels; clear
-        const float v = (float)a * inv;
+    auto conv = [&](int i, unsigned long long a) -> float {  // exact u64 sum -> fp32 pixel (one rounding), stored for the later kernels; clear
+        const float v = (float)((double)a * ACC_INV);
         I[i] = v;
-        if (a != 0u) A[i] = 0u;
+        if (a != 0ull) A[i] = 0ull;
         return v;
     };
     // four independent load pairs in flight per trip: with one pair per trip the loop paid a full memory latency 11 times
     const int npx = (int)n, stride = NSPART * NT;
     int i = part * NT + (int)threadIdx.x;
     for (; i + 3 * stride < npx; i += 4 * stride) {
-        const uint32_t a0 = A[i], a1 = A[i + stride], a2 = A[i + 2 * stride], a3 = A[i + 3 * stride];
+        const unsigned long long a0 = A[i], a1 = A[i + stride], a2 = A[i + 2 * stride], a3 = A[i + 3 * stride];
         const float e0 = E[i], e1 = E[i + stride], e2 = E[i + 2 * stride], e3 = E[i + 3 * stride];
         take(conv(i, a0), e0); take(conv(i + stride, a1), e1); take(conv(i + 2 * stride, a2), e2); take(conv(i + 3 * stride, a3), e3);
     }
@@ -715,30 +781,49 @@ __device__ __forceinline__ double mse_from_moments(const ImgScal& s, double sE, 
 //   contrast (variance): a_r * (2/HW) * (I - mean I)
 //   correlation:         Gn/D + dm*[I==m]/#min + dM*[I==M]/#max,  Gn = b_r*(2/HW)*(E - n)
 // ------------------------------------------------------------------------------------------------
+constexpr int IMG_TPG = 4;        // tiles per k_imgrad workgroup
 __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
         const float* __restrict__ iwe, const float* __restrict__ edges,
         const StatPart* __restrict__ parts, const WinConst* __restrict__ wc,
         const float* __restrict__ gdiv, const double* __restrict__ dgparts,    // delta != 0 only (else unused)
         double* __restrict__ g2parts,          // (B,R,ntiles): this tile's sum of gx^2+gy^2 (contrast energy), a by-product
         float* __restrict__ G,
-        unsigned* __restrict__ gmax)           // (B,R): max |G| as float bits (atomicMax; zeroed by the statistics pass): fixes the
-                                               // fixed-point scale of the gradient accumulators (grad_shift)
+        unsigned* __restrict__ gmax)           // (B,R,ntiles): this tile's max |G| as float bits: fixes the fixed-point scale of the
+                                               // gradient accumulators (gmax_of, grad_shift)
 {
-    __shared__ double g2scratch[NWAVE];
-    __shared__ float gmscratch[NWAVE];
+    // grid (ceil(ntiles / IMG_TPG), R, B): a workgroup walks IMG_TPG consecutive tiles of one image.  The per-image scalars (a
+    // dependent chain of loads, fp64 wave reductions and divisions: ~3 us) are paid once per workgroup instead of once per tile, the
+    // next tile's pixels are in flight while the current one is processed, and the whole image stack is one round of workgroups.
+    __shared__ double g2w[IMG_TPG][NWAVE];
+    __shared__ float gmw[IMG_TPG][NWAVE];
     constexpr int P2 = TS + 4, P1 = TS + 2;
+    constexpr int NPF = (P2 * P2 + NT - 1) / NT;          // pixels of the haloed tile per thread
+    constexpr int NOWN = TS * TS / NT;                    // own pixels per thread
     __shared__ float t[P2][P2 + 1];
     __shared__ float sgx[P1][P1 + 1], sgy[P1][P1 + 1];   // fp32 stencils: inputs (IWE) and output (G) are fp32 images
     __shared__ double sc[9];
     const bool use_div = (ep.delta != 0.0);
-    const int tile = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
-    const int tx = tile % g.tilesX, ty = tile / g.tilesX;
-    const int x0 = tx * TS, y0 = ty * TS;
+    const int grp = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
     const double HW = (double)g.H * (double)g.W;
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
     const float* __restrict__ E = edges + ((size_t)b * g.R + r) * g.H * g.W;
     float* __restrict__ Go = G + ((size_t)b * g.R + r) * g.H * g.W;
     const WinConst& c = wc[b];
+    const int tile0 = grp * IMG_TPG, ntl = min(IMG_TPG, g.ntiles - tile0);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+    float pf[NPF];                                        // the haloed pixels of the NEXT tile, in flight
+    auto prefetch = [&](int tile) {
+        const int x0 = (tile % g.tilesX) * TS, y0 = (tile / g.tilesX) * TS;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int p = threadIdx.x + k * NT;
+            const int ly = p / P2, lx = p % P2;
+            const int y = y0 + ly - 2, x = x0 + lx - 2;
+            pf[k] = (p < P2 * P2 && y >= 0 && y < g.H && x >= 0 && x < g.W) ? I[(size_t)y * g.W + x] : 0.0f;
+        }
+    };
+    prefetch(tile0);
 
     if (threadIdx.x < 64) {
         const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
@@ -769,69 +854,84 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
             sc[7] = s.sI / HW;                               // mean I
         }
     }
-    for (int p = threadIdx.x; p < P2 * P2; p += NT) {
-        const int ly = p / P2, lx = p % P2;
-        const int y = y0 + ly - 2, x = x0 + lx - 2;
-        t[ly][lx] = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? I[(size_t)y * g.W + x] : 0.0f;
-    }
-    __syncthreads();
-    double g2 = 0.0;
-    if (ep.contrast_kind == 0) {
-        float g2f = 0.0f;
-        for (int p = threadIdx.x; p < P1 * P1; p += NT) {
-            const int ly = p / P1, lx = p % P1;
-            const int y = y0 + ly - 1, x = x0 + lx - 1;
-            float gx = 0.0f, gy = 0.0f;
-            if (y >= 0 && y < g.H && x >= 0 && x < g.W) {   // zero outside the image
-                const int cy = ly + 1, cx = lx + 1;
-                gx = 3.0f * (t[cy + 1][cx + 1] - t[cy + 1][cx - 1]) + 10.0f * (t[cy][cx + 1] - t[cy][cx - 1]) + 3.0f * (t[cy - 1][cx + 1] - t[cy - 1][cx - 1]);
-                gy = 3.0f * (t[cy + 1][cx + 1] - t[cy - 1][cx + 1]) + 10.0f * (t[cy + 1][cx] - t[cy - 1][cx]) + 3.0f * (t[cy + 1][cx - 1] - t[cy - 1][cx - 1]);
-            }
-            sgx[ly][lx] = gx; sgy[ly][lx] = gy;
-            if (ly >= 1 && ly <= TS && lx >= 1 && lx <= TS) g2f += gx * gx + gy * gy;   // own pixels only (zero outside the image)
-        }
-        g2 = (double)g2f;
-        __syncthreads();
-    }
-    g2 = block_sum(g2, g2scratch);
-    if (threadIdx.x == 0) g2parts[((size_t)b * g.R + r) * g.ntiles + tile] = g2;
-    const double m = sc[0], M = sc[1], D = sc[2];
-    float gm = 0.0f;
-    for (int p = threadIdx.x; p < TS * TS; p += NT) {
-        const int ly = p / TS, lx = p % TS;
-        const int y = y0 + ly, x = x0 + lx;
-        if (y >= g.H || x >= g.W) continue;
-        const double v = (double)t[ly + 2][lx + 2];
-        double dc;
-        if (ep.contrast_kind == 0) {
-            // adj_Sx(gx) = -conv(gx, Sx), adj_Sy(gy) = -conv(gy, Sy)
-            const int cy = ly + 1, cx = lx + 1;
-            const float ax = 3.0f * (sgx[cy + 1][cx + 1] - sgx[cy + 1][cx - 1]) + 10.0f * (sgx[cy][cx + 1] - sgx[cy][cx - 1])
-                           + 3.0f * (sgx[cy - 1][cx + 1] - sgx[cy - 1][cx - 1]);
-            const float ay = 3.0f * (sgy[cy + 1][cx + 1] - sgy[cy - 1][cx + 1]) + 10.0f * (sgy[cy + 1][cx] - sgy[cy - 1][cx])
-                           + 3.0f * (sgy[cy + 1][cx - 1] - sgy[cy - 1][cx - 1]);
-            dc = -(double)(ax + ay);
-        } else {
-            dc = v - sc[7];
-        }
-        const double n = (v - m) / D;
-        const double e = (double)E[(size_t)y * g.W + x];
-        double gv = sc[3] * dc + sc[4] * (e - n);
-        if (use_div) gv += sc[8] * (double)gdiv[((size_t)b * g.R + r) * g.H * g.W + (size_t)y * g.W + x];
-        if (v == m) gv += sc[5];
-        if (v == M) gv += sc[6];
-        const float gf = (float)gv;
-        Go[(size_t)y * g.W + x] = gf;
-        gm = (gf == gf) ? fmaxf(gm, fabsf(gf)) : INFINITY;
-    }
+
+    for (int k = 0; k < ntl; ++k) {
+        const int tile = tile0 + k;
+        const int x0 = (tile % g.tilesX) * TS, y0 = (tile / g.tilesX) * TS;
+        if (k) __syncthreads();                          // the previous tile's stencils have read t / sgx / sgy
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_down(gm, o, 64));
-    if ((threadIdx.x & 63) == 0) gmscratch[threadIdx.x >> 6] = gm;
+        for (int q = 0; q < NPF; ++q) {
+            const int p = threadIdx.x + q * NT;
+            if (p < P2 * P2) t[p / P2][p % P2] = pf[q];
+        }
+        if (k + 1 < ntl) prefetch(tile + 1);
+        float ev[NOWN];                                  // this thread's edge pixels: in flight during the first stencil
+#pragma unroll
+        for (int q = 0; q < NOWN; ++q) {
+            const int p = threadIdx.x + q * NT;
+            const int y = y0 + p / TS, x = x0 + p % TS;
+            ev[q] = (y < g.H && x < g.W) ? E[(size_t)y * g.W + x] : 0.0f;
+        }
+        __syncthreads();                                 // t complete (and sc, on the first trip)
+        float g2f = 0.0f;
+        if (ep.contrast_kind == 0) {
+            for (int p = threadIdx.x; p < P1 * P1; p += NT) {
+                const int ly = p / P1, lx = p % P1;
+                const int y = y0 + ly - 1, x = x0 + lx - 1;
+                float gx = 0.0f, gy = 0.0f;
+                if (y >= 0 && y < g.H && x >= 0 && x < g.W) {   // zero outside the image
+                    const int cy = ly + 1, cx = lx + 1;
+                    gx = 3.0f * (t[cy + 1][cx + 1] - t[cy + 1][cx - 1]) + 10.0f * (t[cy][cx + 1] - t[cy][cx - 1]) + 3.0f * (t[cy - 1][cx + 1] - t[cy - 1][cx - 1]);
+                    gy = 3.0f * (t[cy + 1][cx + 1] - t[cy - 1][cx + 1]) + 10.0f * (t[cy + 1][cx] - t[cy - 1][cx]) + 3.0f * (t[cy + 1][cx - 1] - t[cy - 1][cx - 1]);
+                }
+                sgx[ly][lx] = gx; sgy[ly][lx] = gy;
+                if (ly >= 1 && ly <= TS && lx >= 1 && lx <= TS) g2f += gx * gx + gy * gy;   // own pixels only (zero outside the image)
+            }
+            __syncthreads();
+        }
+        const double m = sc[0], M = sc[1], D = sc[2];
+        float gm = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NOWN; ++q) {
+            const int p = threadIdx.x + q * NT;
+            const int ly = p / TS, lx = p % TS;
+            const int y = y0 + ly, x = x0 + lx;
+            if (y >= g.H || x >= g.W) continue;
+            const double v = (double)t[ly + 2][lx + 2];
+            double dc;
+            if (ep.contrast_kind == 0) {
+                // adj_Sx(gx) = -conv(gx, Sx), adj_Sy(gy) = -conv(gy, Sy)
+                const int cy = ly + 1, cx = lx + 1;
+                const float ax = 3.0f * (sgx[cy + 1][cx + 1] - sgx[cy + 1][cx - 1]) + 10.0f * (sgx[cy][cx + 1] - sgx[cy][cx - 1])
+                               + 3.0f * (sgx[cy - 1][cx + 1] - sgx[cy - 1][cx - 1]);
+                const float ay = 3.0f * (sgy[cy + 1][cx + 1] - sgy[cy - 1][cx + 1]) + 10.0f * (sgy[cy + 1][cx] - sgy[cy - 1][cx])
+                               + 3.0f * (sgy[cy + 1][cx - 1] - sgy[cy - 1][cx - 1]);
+                dc = -(double)(ax + ay);
+            } else {
+                dc = v - sc[7];
+            }
+            const double n = (v - m) / D;
+            double gv = sc[3] * dc + sc[4] * ((double)ev[q] - n);
+            if (use_div) gv += sc[8] * (double)gdiv[((size_t)b * g.R + r) * g.H * g.W + (size_t)y * g.W + x];
+            if (v == m) gv += sc[5];
+            if (v == M) gv += sc[6];
+            const float gf = (float)gv;
+            Go[(size_t)y * g.W + x] = gf;
+            gm = (gf == gf) ? fmaxf(gm, fabsf(gf)) : INFINITY;
+        }
+        // per-tile by-products: wave partials now, the (fixed-order) sum over the waves after the loop - no barrier per tile
+        double g2 = wave_sum((double)g2f);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_down(gm, o, 64));
+        if (lane == 0) { g2w[k][wv] = g2; gmw[k][wv] = gm; }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < NWAVE; ++i) gm = fmaxf(gm, gmscratch[i]);
-        // max is order-independent: the value every later kernel reads does not depend on who arrives first
-        if (gm > 0.0f) atomicMax(gmax + b * g.R + r, __float_as_uint(gm));
+    if ((int)threadIdx.x < ntl) {
+        const int k = threadIdx.x;
+        double g2 = 0.0; float gm = 0.0f;
+        for (int i = 0; i < NWAVE; ++i) { g2 += g2w[k][i]; gm = fmaxf(gm, gmw[k][i]); }
+        g2parts[((size_t)b * g.R + r) * g.ntiles + tile0 + k] = g2;
+        gmax[((size_t)b * g.R + r) * g.ntiles + tile0 + k] = __float_as_uint(gm);
     }
 }
 
@@ -985,13 +1085,14 @@ __global__ __launch_bounds__(NT) void k_divgrad(Geom g, const float* __restrict_
 // The G window is staged in LDS with the same bounding box as the forward.  2-DoF theta (direct11): every thread sums its events in
 // fp64 in a fixed order, the workgroup reduces them in a fixed order and STORES its partial in its own slot (k_final adds the
 // slots in index order).  Otherwise: per-pixel sums are accumulated in an LDS copy of the source tile as i64 fixed point
-// (ds_add_u64; scale grad_shift) and flushed with i64 global atomics.  Both are bit-reproducible.
+// (ds_add_u64; scale grad_shift_pixel) and flushed with i64 global atomics.  Both are bit-reproducible.
 // ------------------------------------------------------------------------------------------------
-template <int TM>      // TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
-__global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
+template <int TM, int WIDE>      // TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
+__global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE: 61-bit fixed point per event (tiny windows, see grad_shift_pixel)
         const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
         const double* __restrict__ Theta, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
         const float* __restrict__ G,           // (B,R,H,W)
+        const Window* __restrict__ wins,       // (n_items, R) windows of this evaluation
         long long* __restrict__ gTheta,        // (B,H,W,2) i64 fixed point, zero on entry (cleared by its consumer)
         int direct11, double* __restrict__ g11,                     // 2-DoF theta: (n_items, R, 2) per-workgroup partials of dL/dtheta
         const WinConst* __restrict__ wc, const unsigned* __restrict__ gmax,   // scale of the i64 accumulators (grad_shift)
@@ -1004,12 +1105,12 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     __shared__ double red11[NWAVE];
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(lds + g.wincap);   // i64 fixed point: ds_add_u64 (3.7 lane-ops/clk/CU; ds_add_f32: 0.33)
     double2* thtile = reinterpret_cast<double2*>(lds + g.wincap + (direct11 ? 0 : TS * TS * 4));
-    double sum11x = 0.0, sum11y = 0.0;          // direct11: this thread's share of sum_e -dt * dL/dw
+    float f11x = 0.0f, f11y = 0.0f;             // direct11: this thread's share of sum_e -dt * dL/dw
     int item, r;
     if (!block_to_work(n_items, g.R, item, r)) return;
     const Item it = items[item];
     const double tau = edge_ts[it.win * g.R + r];
-    const Window wn = item_window(g, it, tmm + ((size_t)it.win * g.ntiles + it.tile) * 4, tau);
+    const Window wn = wins[(size_t)item * g.R + r];
     const float* __restrict__ Gi = G + ((size_t)it.win * g.R + r) * g.H * g.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {      // the usual case: window inside the image
@@ -1027,8 +1128,9 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
     }
     double gscale = 0.0;                          // 2^eg of this window's gradient accumulators
     if (!direct11) {
+        __shared__ unsigned gms[NWAVE];
         for (int i = threadIdx.x; i < TS * TS * 2; i += NT) accum[i] = 0ull;
-        gscale = ldexp(1.0, grad_shift(wc[it.win], gmax + it.win * g.R, g.R));
+        gscale = ldexp(1.0, grad_shift_pixel(wc[it.win], gmax_of(gmax + (size_t)it.win * g.R * g.ntiles, g.R * g.ntiles, gms), g.R, WIDE != 0));
     }
     const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
@@ -1085,28 +1187,28 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
                 }
             }
         }
-        // separable: column sums weighted by ky (and ky*qy), then the kx (and kx*qx) combination
-        float gwx = 0.0f, gwy = 0.0f;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const float qx = (float)(dx - 1) - fx;
-            float cs = 0.0f, csq = 0.0f;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const float qy = (float)(dy - 1) - fy;
-                const float t = gv[dy][dx] * ky[dy];
-                cs += t; csq += t * qy;
-            }
-            gwx += cs * kx[dx] * qx;
-            gwy += csq * kx[dx];
-        }
-        if (direct11) {          // theta (1,1,2): Theta is constant, dL/dtheta = sum over all events; no per-pixel image needed
-            sum11x -= dt * (double)gwx; sum11y -= dt * (double)gwy;
+        // dL/dwx = sum_dx Wx[dx] (sum_dy Ky[dy] G[dy][dx]),  dL/dwy = sum_dx Kx[dx] (sum_dy Wy[dy] G[dy][dx]),  W[d] = K[d] ((d - 1) - f):
+        // 30 multiply-adds per event instead of the 42 of the tap-by-tap form
+        const float wx0 = fmaf(-kx[0], fx, -kx[0]), wx1 = -kx[1] * fx, wx2 = fmaf(-kx[2], fx, kx[2]);
+        const float wy0 = fmaf(-ky[0], fy, -ky[0]), wy1 = -ky[1] * fy, wy2 = fmaf(-ky[2], fy, ky[2]);
+        const float c0 = fmaf(ky[2], gv[2][0], fmaf(ky[1], gv[1][0], ky[0] * gv[0][0]));
+        const float c1 = fmaf(ky[2], gv[2][1], fmaf(ky[1], gv[1][1], ky[0] * gv[0][1]));
+        const float c2 = fmaf(ky[2], gv[2][2], fmaf(ky[1], gv[1][2], ky[0] * gv[0][2]));
+        const float d0 = fmaf(wy2, gv[2][0], fmaf(wy1, gv[1][0], wy0 * gv[0][0]));
+        const float d1 = fmaf(wy2, gv[2][1], fmaf(wy1, gv[1][1], wy0 * gv[0][1]));
+        const float d2 = fmaf(wy2, gv[2][2], fmaf(wy1, gv[1][2], wy0 * gv[0][2]));
+        const float gwx = fmaf(wx2, c2, fmaf(wx1, c1, wx0 * c0));
+        const float gwy = fmaf(kx[2], d2, fmaf(kx[1], d1, kx[0] * d0));
+        if (direct11) {          // theta (1,1,2): Theta is constant, dL/dtheta = sum over all events; no per-pixel image needed.
+            // fp32 over the thread's own <= 32 terms (their rounding errors are independent across 10^6 threads and average out:
+            // measured 1e-9 relative on the gradient), fp64 from there on
+            const float ndt = (float)(-dt);
+            f11x = fmaf(ndt, gwx, f11x); f11y = fmaf(ndt, gwy, f11y);
         } else {
             unsigned long long* a = accum + ((((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)) << 1);
             const double sdt = -dt * gscale;
-            atomicAdd(a, (unsigned long long)fix64(sdt * (double)gwx));
-            atomicAdd(a + 1, (unsigned long long)fix64(sdt * (double)gwy));
+            atomicAdd(a, (unsigned long long)(WIDE ? fix64_wide(sdt * (double)gwx) : fix64(sdt * (double)gwx)));
+            atomicAdd(a + 1, (unsigned long long)(WIDE ? fix64_wide(sdt * (double)gwy) : fix64(sdt * (double)gwy)));
         }
     };
     // a plain strided loop: with 8 waves per SIMD the loads are hidden by occupancy; the renamed-register pipeline of
@@ -1117,8 +1219,8 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,
         gather_ev(ev);
     }
     if (direct11) {
-        sum11x = block_sum(sum11x, red11);
-        sum11y = block_sum(sum11y, red11);
+        double sum11x = block_sum((double)f11x, red11);
+        double sum11y = block_sum((double)f11y, red11);
         if (threadIdx.x == 0) {          // own slot, plain store, written unconditionally: nothing to clear, nothing to order
             double* dst = g11 + ((size_t)item * g.R + r) * 2;
             dst[0] = sum11x; dst[1] = sum11y;
@@ -1343,6 +1445,39 @@ __global__ void k_mask(Geom g, const Item* __restrict__ items, int n_items, cons
     }
 }
 
+// k_tile_counts: the same mask, plus the largest number of events on one source pixel (WinConst.cntmax), per (tile, window):
+// LDS histogram of the tile's events.  grid (ntiles, B).  cntmax (B) zeroed beforehand (atomicMax: order-independent).
+__global__ __launch_bounds__(NT) void k_tile_counts(Geom g, const int32_t* __restrict__ tilebase, const int32_t* __restrict__ tilecount,
+                                                     const uint32_t* __restrict__ ev_xy, uint8_t* __restrict__ mask, unsigned* __restrict__ cntmax)
+{
+    __shared__ unsigned hist[TS * TS];
+    __shared__ unsigned wmax[NWAVE];
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int x0 = (tile % g.tilesX) * TS, y0 = (tile / g.tilesX) * TS;
+    for (int i = threadIdx.x; i < TS * TS; i += NT) hist[i] = 0u;
+    __syncthreads();
+    const int base = tilebase[(size_t)b * g.ntiles + tile], cnt = tilecount[(size_t)b * g.ntiles + tile];
+    for (int i = threadIdx.x; i < cnt; i += NT) {
+        const uint32_t xy = ev_xy[base + i];
+        atomicAdd(&hist[((xy >> 11) & (31u << 5)) | (xy & 31u)], 1u);
+    }
+    __syncthreads();
+    unsigned m = 0u;
+    uint8_t* mk = mask + (size_t)b * g.H * g.W;
+    for (int i = threadIdx.x; i < TS * TS; i += NT) {
+        const unsigned h = hist[i];
+        if (h) { mk[(size_t)(y0 + (i >> 5)) * g.W + x0 + (i & 31)] = 1; m = max(m, h); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_down((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < NWAVE; ++i) m = max(m, wmax[i]);
+        if (m) atomicMax(cntmax + b, m);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_tv: total variation of the event-masked flow (regularizers.py:14-38) and its unscaled gradient image.
 //   F = Theta*mask;  TV = 0.25*sum(|Fx*Sx|+|Fx*Sy|+|Fy*Sx|+|Fy*Sy|) / (#pixels with any non-zero term + eps)
@@ -1478,12 +1613,13 @@ constexpr int PROJ_CELLS = 1024;
 __host__ __device__ __forceinline__ int tv_shift(int H, int W) {
     int e = 0;
     while ((double)(1ull << e) <= 256.0 * (double)H * (double)W) ++e;
-    return 50 - e;
+    return 61 - e;
 }
-__global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, int src0,
+__global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, int src0, int wide,
         const double* __restrict__ AH, const double* __restrict__ AW,
         const int2* __restrict__ rowtap, const int2* __restrict__ coltap,
         long long* __restrict__ gTheta, const double* __restrict__ tvg,
+        const WinConst* __restrict__ wc, const unsigned* __restrict__ gmax,
         long long* __restrict__ gth_main, long long* __restrict__ gth_tv)   // (B,cap) each, zero on entry (k_final clears)
 {
     __shared__ double scratch[NWAVE];
@@ -1503,9 +1639,12 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
     const int ilo = rng[0], ihi = rng[1], jlo = rng[2], jhi = rng[3];
     const int ni = max(ihi - ilo, 0), nj = max(jhi - jlo, 0), ncell = ni * nj;
     unsigned long long* __restrict__ out = reinterpret_cast<unsigned long long*>(src == 0 ? gth_main : gth_tv) + (size_t)b * cap;
-    // src 0: the pixel values already ARE integers at the accumulator scale, and the weights only shrink them: scale 1.
+    // src 0: integers at the fine per-pixel scale -> the coarser cell scale (one rounding per pixel and weight).
     // src 1: fp64 TV gradient image -> fixed point at tv_shift.
-    const double scale = (src == 0) ? 1.0 : ldexp(1.0, tv_shift(g.H, g.W));
+    __shared__ unsigned gms[NWAVE];
+    const double gm = gmax_of(gmax + (size_t)b * g.R * g.ntiles, g.R * g.ntiles, gms);
+    const double scale = (src == 0) ? ldexp(1.0, grad_shift(wc[b], gm, g.R) - grad_shift_pixel(wc[b], gm, g.R, wide != 0))
+                                    : ldexp(1.0, tv_shift(g.H, g.W));
     const bool use_lds = (ncell > 1 && ncell <= PROJ_CELLS);
     if (use_lds) {
         for (int i = threadIdx.x; i < ncell * 2; i += NT) cells[i] = 0ull;
@@ -1521,7 +1660,7 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
             const long long ix = gTheta[o], iy = gTheta[o + 1];
             if (ix == 0 && iy == 0) continue;
             gTheta[o] = 0; gTheta[o + 1] = 0;       // consumed: zero again for the next evaluation
-            vx = (double)ix; vy = (double)iy;       // exact: |.| < 2^51
+            vx = (double)ix * scale; vy = (double)iy * scale;       // (double)ix exact for |.| < 2^53 (always, unless `wide`)
         } else {
             vx = tvg[o] * scale; vy = tvg[o + 1] * scale;
             if (vx == 0.0 && vy == 0.0) continue;
@@ -1534,10 +1673,10 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
                 if (ncell == 1) { sx1 += wt * vx; sy1 += wt * vy; }
                 else if (use_lds) {
                     unsigned long long* c = cells + ((i - ilo) * nj + (j - jlo)) * 2;
-                    atomicAdd(c, (unsigned long long)fix64(wt * vx)); atomicAdd(c + 1, (unsigned long long)fix64(wt * vy));
+                    atomicAdd(c, (unsigned long long)fix64_wide(wt * vx)); atomicAdd(c + 1, (unsigned long long)fix64_wide(wt * vy));
                 } else {
-                    atomicAdd(out + ((size_t)i * w + j) * 2, (unsigned long long)fix64(wt * vx));
-                    atomicAdd(out + ((size_t)i * w + j) * 2 + 1, (unsigned long long)fix64(wt * vy));
+                    atomicAdd(out + ((size_t)i * w + j) * 2, (unsigned long long)fix64_wide(wt * vx));
+                    atomicAdd(out + ((size_t)i * w + j) * 2 + 1, (unsigned long long)fix64_wide(wt * vy));
                 }
             }
         }
@@ -1546,8 +1685,8 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
         sx1 = block_sum(sx1, scratch);
         sy1 = block_sum(sy1, scratch);
         if (threadIdx.x == 0) {
-            if (sx1 != 0.0) atomicAdd(out + ((size_t)ilo * w + jlo) * 2, (unsigned long long)fix64(sx1));
-            if (sy1 != 0.0) atomicAdd(out + ((size_t)ilo * w + jlo) * 2 + 1, (unsigned long long)fix64(sy1));
+            if (sx1 != 0.0) atomicAdd(out + ((size_t)ilo * w + jlo) * 2, (unsigned long long)fix64_wide(sx1));
+            if (sy1 != 0.0) atomicAdd(out + ((size_t)ilo * w + jlo) * 2 + 1, (unsigned long long)fix64_wide(sy1));
         }
     } else if (use_lds) {
         __syncthreads();
@@ -1662,8 +1801,17 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
             // 2-DoF: add the partials of this window's k_gather workgroups in index order (fixed strided order per thread, then
             // the fixed tree of block_sum): bit-reproducible without any atomic
             const int lo = win_item0[b], hi = (b + 1 < g.B) ? win_item0[b + 1] : n_items;
+            // (four loads in flight per trip: one workgroup adds ~7500 partials per window, and a loop that waits for every load
+            // pays a memory latency 30 times)
+            const double2* __restrict__ q = reinterpret_cast<const double2*>(g11);
+            const int kend = hi * g11_per_item;
             double sx = 0.0, sy = 0.0;
-            for (int k = lo * g11_per_item + threadIdx.x; k < hi * g11_per_item; k += NT) { sx += g11[2 * (size_t)k]; sy += g11[2 * (size_t)k + 1]; }
+            int k = lo * g11_per_item + threadIdx.x;
+            for (; k + 3 * NT < kend; k += 4 * NT) {
+                const double2 a0 = q[k], a1 = q[k + NT], a2 = q[k + 2 * NT], a3 = q[k + 3 * NT];
+                sx += (a0.x + a1.x) + (a2.x + a3.x); sy += (a0.y + a1.y) + (a2.y + a3.y);
+            }
+            for (; k < kend; k += NT) { const double2 a = q[k]; sx += a.x; sy += a.y; }
             sx = block_sum(sx, scratch);
             sy = block_sum(sy, scratch);
             if (threadIdx.x == 0) {
@@ -1674,7 +1822,8 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
                 grad_out[(size_t)b * 2] = sx; grad_out[(size_t)b * 2 + 1] = sy;
             }
         } else {
-            const double inv = ldexp(1.0, -grad_shift(c, gmax + b * g.R, g.R));
+            __shared__ unsigned gms[NWAVE];
+            const double inv = ldexp(1.0, -grad_shift(c, gmax_of(gmax + (size_t)b * g.R * g.ntiles, g.R * g.ntiles, gms), g.R));
             for (int i = threadIdx.x; i < n; i += NT) {
                 double v = (double)gth_main[(size_t)b * gth_cap + i] * inv;
                 gth_main[(size_t)b * gth_cap + i] = 0;
@@ -1686,14 +1835,15 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
 }
 
 // dense (identity resample) gradient: grad = gTheta * 2^-eg + tv_scale * tvg; consumes (clears) the i64 image.  grid-stride, grid (nblk, B)
-__global__ void k_final_dense(Geom g, int use_tv, long long* __restrict__ gTheta, const double* __restrict__ tvg,
+__global__ void k_final_dense(Geom g, int use_tv, int wide, long long* __restrict__ gTheta, const double* __restrict__ tvg,
                               const WinConst* __restrict__ wc, const unsigned* __restrict__ gmax,
                               const OutScal* __restrict__ outs, double* __restrict__ grad_out)
 {
     const int b = blockIdx.y;
     const size_t n = (size_t)g.H * g.W * 2;
     const double s = outs[b].tv_scale;
-    const double inv = ldexp(1.0, -grad_shift(wc[b], gmax + b * g.R, g.R));
+    __shared__ unsigned gms[NWAVE];
+    const double inv = ldexp(1.0, -grad_shift_pixel(wc[b], gmax_of(gmax + (size_t)b * g.R * g.ntiles, g.R * g.ntiles, gms), g.R, wide != 0));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const long long q = gTheta[b * n + i];
         if (q != 0) gTheta[b * n + i] = 0;

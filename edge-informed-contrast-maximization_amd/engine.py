@@ -207,13 +207,8 @@ class Engine:
 
     def iwe_tensor(self):
         """torch view of the IWE accumulator (B,R,H,W) in HBM, for an RCCL all-reduce(sum) between the two halves.  The engine sums
-        the IWE in u32 fixed point (exact, order-independent); the view is int32 because RCCL / gloo reduce signed integers and
-        two's-complement addition is the same operation."""
-        return self._device_view(self._lib.eincm_iwe_device_ptr, '<i4', 4, (self.B, self.R, self.H, self.W))
-
-    def set_iwe_scale_events(self, n_events_per_window):
-        """Event-sharded mode: the fixed-point scale of the IWE accumulator must hold the events of ALL shards of a window."""
-        self._check(self._lib.eincm_set_iwe_scale_events(self._ctx, int(n_events_per_window)))
+        pixel * 2^30 as 64-bit integers (exact, order-independent); the view is int64 (values stay below 2^63)."""
+        return self._device_view(self._lib.eincm_iwe_device_ptr, '<i8', 8, (self.B, self.R, self.H, self.W))
 
     def mask_tensor(self):
         """torch view of the event-presence mask (B,H,W) uint8."""

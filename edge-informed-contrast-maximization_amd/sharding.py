@@ -62,8 +62,8 @@ def shard_events(n_events, rank, world_size):
 class ShardedEngine:
     """Event-sharded evaluation: every rank stages ITS slice of each window's events (edges replicated) in its own Engine.
     The IWE is additive over events (src/utils/event_utils.py:59 is a pure sum), so one exchange step suffices per
-    evaluation: all-reduce(sum) of the (B,R,H,W) u32 fixed-point IWE accumulator between k_splat and the statistics pass
-    (0.36 MB x R at 260x346, 1.2 MB x R at 480x640; integer, so the sum is exact and independent of the reduction order),
+    evaluation: all-reduce(sum) of the (B,R,H,W) int64 fixed-point IWE accumulator between k_splat and the statistics pass
+    (0.72 MB x R at 260x346, 2.5 MB x R at 480x640; integer, so the sum is exact and independent of the reduction order),
     then every rank finishes on the summed stack and the small (h,w,2) gradients are summed.
     The loss is identical on every rank.  Collectives go through torch.distributed's default group: backend 'nccl'
     (= RCCL over xGMI) reduces the engine's HBM buffer in place; 'gloo' (CPU rehearsal) bounces through host memory.
@@ -93,16 +93,7 @@ class ShardedEngine:
 
     def set_windows(self, local_windows):
         """local_windows: this rank's (xs, ys, ts, edges, edge_ts) per window — its slice of the events, the full edges."""
-        import torch
         D = self.dist
-        # one fixed-point scale on every rank: the largest window's event count over all shards
-        n_max = torch.tensor([max(len(w[0]) for w in local_windows)], dtype=torch.int64)
-        tot = n_max.clone()
-        if self.on:
-            if self.gpu_collectives:
-                tot = tot.cuda()
-            D.all_reduce(tot, op=D.ReduceOp.SUM)            # sum of the per-rank maxima bounds every window's total
-        self.eng.set_iwe_scale_events(int(tot.item()))
         self.eng.set_windows(local_windows, defer_constants=True)
         self._allreduce_(self.eng.mask_tensor(), D.ReduceOp.MAX)          # TV needs the global event mask
         self.eng.forward_iwe(None, None)                                   # theta = 0: partial IUE of this shard

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define EINCM_ABI_VERSION 2   /* 2: eincm_iwe_device_ptr hands out the u32 fixed-point accumulator; eincm_set_iwe_scale_events */
+#define EINCM_ABI_VERSION 2   /* 2: eincm_iwe_device_ptr hands out the u64 fixed-point accumulator of the IWE stack */
 
 #define EINCM_OK               0
 #define EINCM_ERR_ARG         -1   /* bad argument (shape, null pointer, out-of-range event coordinate) */
@@ -51,7 +51,7 @@ extern "C" {
 
 /* eincm_create flags */
 #define EINCM_CF_TIMING     1u     /* bracket every kernel with HIP events (eincm_get_timings); costs ~10 % of a step */
-#define EINCM_CF_TIMING_DOMINANT 2u /* bracket only the dominant kernel (k_splat) and the whole evaluation: 4 event records */
+#define EINCM_CF_TIMING_DOMINANT 2u /* bracket only the two event kernels (k_splat, k_gather) and the whole evaluation: 6 event records */
 
 typedef struct eincm_ctx eincm_ctx;
 
@@ -195,20 +195,17 @@ int eincm_get_timings_total(eincm_ctx* ctx, eincm_timings* sum, int64_t* n_evals
 /* Event-sharded evaluation: the events of the SAME windows are split over several contexts (one per GPU);
  * edges and edge_ts are replicated.  The IWE is additive over events (src/utils/event_utils.py:59 is a pure sum), so
  *   every shard:  eincm_forward_iwe(theta)            k_theta + k_splat on its own events; returns stream-synchronised
- *   caller:       all-reduce(sum) of the IWE stacks   (RCCL on eincm_iwe_device_ptr; (n_windows, n_refs, H, W) uint32/int32:
- *                                                      the engine accumulates the IWE in u32 fixed point so that sums are exact
- *                                                      and order-independent; wrap-around integer addition is what is wanted)
+ *   caller:       all-reduce(sum) of the IWE stacks   (RCCL on eincm_iwe_device_ptr; (n_windows, n_refs, H, W) int64: the engine
+ *                                                      accumulates pixel * 2^30 as 64-bit integers, so the sum over shards is exact
+ *                                                      and independent of the reduction order)
  *   every shard:  eincm_finish_loss_grad              statistics ... gradient on the summed stack
- * Every shard must use the same fixed-point scale: call eincm_set_iwe_scale_events(total events of the largest window over ALL
- * shards) before eincm_set_windows_ex (the scale 2^k is the largest with 0.16 * events * 2^k <= 2^32, so no pixel can overflow).
  * gives the same value on every shard and gradients that SUM to the full gradient (pass EINCM_PF_NO_TV_GRAD on all but
  * one shard).  Staging: eincm_set_windows_ex(..., EINCM_SW_DEFER_CONSTANTS), all-reduce(max) of the event masks
  * (eincm_mask_device_ptr, uint8), eincm_forward_iwe(theta = NULL), all-reduce(sum) of the IWE stacks, eincm_finish_constants. */
 int eincm_forward_iwe(eincm_ctx* ctx, const double* theta, int h, int w, const eincm_params* p, int want_grad);
 int eincm_finish_loss_grad(eincm_ctx* ctx, double* value, double* grad, eincm_aux* aux);
 int eincm_finish_constants(eincm_ctx* ctx);
-int eincm_iwe_device_ptr(eincm_ctx* ctx, void** dptr, int64_t* n_words);
-int eincm_set_iwe_scale_events(eincm_ctx* ctx, int64_t n_events_per_window);   /* 0 = each window's own event count (default) */
+int eincm_iwe_device_ptr(eincm_ctx* ctx, void** dptr, int64_t* n_words);   /* n_words 64-bit integers */
 int eincm_mask_device_ptr(eincm_ctx* ctx, void** dptr, int64_t* n_bytes);
 
 /* ---- the step that produces `edges`, and the tiled objectives ------------------------------------ */

@@ -1,4 +1,4 @@
-"""Bit-reproducibility of the HIP path.  Every accumulation that crosses workgroups is integer (u32 IWE accumulator, i64 gradient
+"""Bit-reproducibility of the HIP path.  Every accumulation that crosses workgroups is integer (u64 IWE accumulator, i64 gradient
 accumulators) or an ordered fp64 sum, and staging is a stable sort, so repeating an evaluation - or staging the same window again,
 or evaluating it in a fresh context - gives the same bits.  The reference asks for float64 because "BFGS converges correctly only with
 float64" (/root/reference/src/experiments/e00/configs/main.yaml:34); what its optimiser needs from the objective is that the same theta

@@ -201,3 +201,19 @@ def test_sparse_flow_error():
     assert r['errors']['A1PE'] == pytest.approx(100.0 / n) and r['errors']['A3PE'] == 0.0
     flow = evaluation.per_pix_theta_to_flow(np.ones((H, W, 2)), np.array([1, 3]), np.array([2, 2]))
     assert flow.sum() == 4.0 and flow[2, 1, 0] == 1.0 and flow[2, 3, 1] == 1.0
+
+
+def test_bench_argument_paths():
+    """bench.py: the two decompositions select their BASELINE.json configurations (C4 share / C5) from --mode alone."""
+    import bench
+    a = bench.parse_args([])
+    assert (a.mode, a.events, a.refs, a.sensor, a.gpus, a.steps, a.warmup) == ('windows', 1_000_000, 5, '260x346', 1, 20, 3)
+    s = bench.parse_args(['--mode', 'event-sharded', '--gpus', '2'])
+    assert (s.mode, s.events, s.refs, s.sensor, s.solve_iters) == ('event-sharded', 10_000_000, 3, '480x640', 50)
+    s2 = bench.parse_args(['--mode', 'event-sharded', '--events', '200000', '--sensor', '120x160'])
+    assert (s2.events, s2.sensor) == (200000, '120x160')
+    # SURVEY 8(d): 2*8*N + 20*R*H*W per window and evaluation; one event kernel: 8*N + 4*R*H*W
+    assert bench.algorithmic_bytes(1_000_000, 5, 260, 346, False) == 16_000_000 + 20 * 5 * 260 * 346
+    assert bench.event_kernel_algorithmic_bytes(1_000_000, 5, 260, 346) == 8_000_000 + 4 * 5 * 260 * 346
+    r = bench.kernel_roofline('k_x', 0.1, 80_000_000, None)
+    assert r['achieved'] == pytest.approx(800.0) and r['frac'] == pytest.approx(0.1) and r['peak'] == 8000.0
