@@ -62,7 +62,6 @@ struct eincm_ctx {
     int n_items_s = 0; int seg_s = 0; int seg_s_used = 0;
     int wincap = WIN_CAP_DEFAULT;
     bool wincap_fixed = false;     // EINCM_WINCAP pins the capacity; otherwise it is chosen per evaluation from max|theta|
-    bool fused11 = false;          // 2-DoF theta: k_gather11 (all reference times of a segment in one workgroup), EINCM_GATHER11=1; default k_gather
     bool chunk_fixed = false;      // EINCM_CHUNK given
     int g11_per_item = 1;          // slots per segment in d_g11 written by the last gather launch
     // device-side staging (eincm_binning.hip.h)
@@ -509,7 +508,7 @@ int eval_end_launch(eincm_ctx* c) {
             if (div_grad)
                 hipLaunchKernelGGL(k_divgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_parts,
                                    c->d_gdiv, c->d_dgparts);
-            hipLaunchKernelGGL(k_imgrad, dim3((g.ntiles + IMG_TPG - 1) / IMG_TPG, g.R, g.B), dim3(NT), 0, c->stream, g, ep, c->d_iwe, c->d_edges,
+            hipLaunchKernelGGL(k_imgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, ep, c->d_iwe, c->d_edges,
                                c->d_parts, c->d_wc, c->d_gdiv, c->d_dgparts, c->d_g2parts, c->d_G, c->d_gmax);
         }
         {
@@ -519,24 +518,7 @@ int eval_end_launch(eincm_ctx* c) {
                     g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), c->stream, \
                     g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_wins, c->d_gTheta, \
                     direct11 ? 1 : 0, c->d_g11, c->d_wc, c->d_gmax, direct11 ? THETA_CONST : THETA_TILE
-                if (direct11 && c->fused11) {
-                    // all reference times of a segment in one workgroup: RF windows of `cap` floats in LDS (cap chosen so that they fit)
-                    const int RF = std::min(g.R, G11_RF);
-                    const int nrg = (g.R + RF - 1) / RF;
-                    const int cap = std::min(g.wincap, (int)(65536 / sizeof(float)) / RF / 4 * 4);
-                    const unsigned grid = (unsigned)(((c->n_items * nrg + NXCD - 1) / NXCD) * NXCD);
-#define G11_ARGS dim3(grid), dim3(NT), (size_t)RF * cap * sizeof(float), c->stream, g, c->n_items, nrg, cap, c->d_items, c->d_xy, c->d_t, \
-                 c->d_tmm, c->d_edge_ts, c->d_G, c->d_g11
-                    switch (RF) {
-                        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather11<1>), G11_ARGS); break;
-                        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather11<2>), G11_ARGS); break;
-                        case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather11<3>), G11_ARGS); break;
-                        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather11<4>), G11_ARGS); break;
-                        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather11<5>), G11_ARGS); break;
-                    }
-#undef G11_ARGS
-                    c->g11_per_item = nrg;
-                } else if (direct11) {
+                if (direct11) {
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_CONST, 0>), GATHER_ARGS);
                     c->g11_per_item = g.R;
                 } else if (wide) {
@@ -729,7 +711,6 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     c->cflags = flags;
     if (const char* s = getenv("EINCM_CHUNK")) { int v = atoi(s); if (v >= NT && v <= MAX_CHUNK) { c->chunk = (v / NT) * NT; c->chunk_fixed = true; } }
     if (const char* s = getenv("EINCM_SEG")) { int v = atoi(s); if (v >= 64 && v <= MAX_SEG) c->seg = v; }
-    if (const char* s = getenv("EINCM_GATHER11")) c->fused11 = atoi(s) != 0;
     if (const char* s = getenv("EINCM_SEG_SPLAT")) { int v = atoi(s); if (v >= 64 && v <= MAX_SEG) c->seg_s = v; }
     if (const char* s = getenv("EINCM_WINCAP")) { int v = atoi(s); if (v >= 1024 && v <= 6912) { c->wincap = (v / 4) * 4; c->wincap_fixed = true; } }
     if (c->seg_s > c->chunk && c->wincap > 4608) c->wincap = 4608;       // two LDS windows in k_splat's long-segment form

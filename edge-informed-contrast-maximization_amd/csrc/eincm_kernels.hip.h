@@ -259,25 +259,24 @@ __device__ __forceinline__ void warp_axis(int x, double v, double dt, int& ir, f
     ir = min(max(ri, -(1 << 20)), 1 << 20);          // one v_med3_i32; |w| beyond any sensor (W, H <= 32767): every tap is dropped
 }
 
-typedef float f2v __attribute__((ext_vector_type(2)));   // (x-axis value, y-axis value): lowers to v_pk_mul_f32 / v_pk_fma_f32
+// (x-axis value, y-axis value).  A plain struct on purpose: as an ext_vector_type the pairs lower to v_pk_mul_f32 / v_pk_fma_f32, and on
+// gfx950 packed fp32 issues at half the rate of scalar fp32 AND needs register-pair shuffles: building with the SLP vectoriser off
+// (which packs the gather's combination the same way) took k_gather from 120 to 106 us.
+struct f2v { float x, y; };
 
-// Separable 3-tap weights of BOTH axes at once, packed fp32: k(d) = exp(-0.5 (d - f)^2) = exp(-0.5 f^2) exp(d f) exp(-0.5 d^2),
+// Separable 3-tap weights of BOTH axes: k(d) = exp(-0.5 (d - f)^2) = exp(-0.5 f^2) exp(d f) exp(-0.5 d^2),
 // d = -1, 0, 1 (event_utils.py:52-56).  The y weights carry `scale_y` (1/(2 pi), times the fixed-point scale in k_splat).
-// 4 v_exp_f32 + 2 v_rcp_f32 (1 ulp each) + 7 packed multiplies.
+// 4 v_exp_f32 + 2 v_rcp_f32 (1 ulp each) + 13 multiplies.
 __device__ __forceinline__ void taps3x2(float fx, float fy, float scale_y, f2v& km, f2v& k0, f2v& kp) {
     constexpr float L2E = 1.4426950408889634f;
-    const f2v f = {fx, fy};
-    const f2v a = (f * f) * (-0.5f * L2E);
-    const f2v b = f * L2E;
-    f2v e0 = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
-    const f2v ep = {__builtin_amdgcn_exp2f(b.x), __builtin_amdgcn_exp2f(b.y)};
-    const f2v em = {__builtin_amdgcn_rcpf(ep.x), __builtin_amdgcn_rcpf(ep.y)};
-    const f2v sc = {1.0f, scale_y};
-    e0 = e0 * sc;
-    const f2v c = e0 * EXP_M05;
-    km = c * em;                // d = -1
-    k0 = e0;
-    kp = c * ep;                // d = +1
+    const float e0x = __builtin_amdgcn_exp2f((fx * fx) * (-0.5f * L2E));
+    const float e0y = __builtin_amdgcn_exp2f((fy * fy) * (-0.5f * L2E)) * scale_y;
+    const float epx = __builtin_amdgcn_exp2f(fx * L2E), epy = __builtin_amdgcn_exp2f(fy * L2E);
+    const float emx = __builtin_amdgcn_rcpf(epx), emy = __builtin_amdgcn_rcpf(epy);
+    const float cx = e0x * EXP_M05, cy = e0y * EXP_M05;
+    km.x = cx * emx; km.y = cy * emy;            // d = -1
+    k0.x = e0x; k0.y = e0y;
+    kp.x = cx * epx; kp.y = cy * epy;            // d = +1
 }
 
 struct EvReg { uint32_t xy; double t; };   // one event in flight through the software pipeline of the event kernels
@@ -504,28 +503,23 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
         const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;        // window coords of the top-left tap
         if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
             uint32_t* p = ldsu + __mul24(ly, wn.ww) + lx;
-            // 3x3 products ky[dy]*kx[dx] + 0.5 as 4 packed FMAs + 1 scalar, then truncating converts
-            const f2v half = {0.5f, 0.5f};
-            const f2v kx01 = {km.x, k0.x};
-            const f2v r0 = kx01 * km.y + half, r1 = kx01 * k0.y + half, r2 = kx01 * kp.y + half;
-            const f2v ky01 = {km.y, k0.y};
-            const f2v c2 = ky01 * kp.x + half;       // column dx = 2 of rows 0, 1
-            const float c22 = fmaf(kp.y, kp.x, 0.5f);
+            // 3x3 products ky[dy]*kx[dx] + 0.5 (scalar FMAs: packed ones are slower on gfx950), then truncating converts
             uint32_t* p1 = p + wn.ww; uint32_t* p2 = p1 + wn.ww;
-            atomicAdd(p, (uint32_t)r0.x); atomicAdd(p + 1, (uint32_t)r0.y); atomicAdd(p + 2, (uint32_t)c2.x);
-            atomicAdd(p1, (uint32_t)r1.x); atomicAdd(p1 + 1, (uint32_t)r1.y); atomicAdd(p1 + 2, (uint32_t)c2.y);
-            atomicAdd(p2, (uint32_t)r2.x); atomicAdd(p2 + 1, (uint32_t)r2.y); atomicAdd(p2 + 2, (uint32_t)c22);
+            atomicAdd(p, fix_u32(km.y, km.x)); atomicAdd(p + 1, fix_u32(km.y, k0.x)); atomicAdd(p + 2, fix_u32(km.y, kp.x));
+            atomicAdd(p1, fix_u32(k0.y, km.x)); atomicAdd(p1 + 1, fix_u32(k0.y, k0.x)); atomicAdd(p1 + 2, fix_u32(k0.y, kp.x));
+            atomicAdd(p2, fix_u32(kp.y, km.x)); atomicAdd(p2 + 1, fix_u32(kp.y, k0.x)); atomicAdd(p2 + 2, fix_u32(kp.y, kp.x));
         } else {
             const float kx[3] = {km.x, k0.x, kp.x}, ky[3] = {km.y, k0.y, kp.y};
+            const int sx = irx, sy = iry, lxs = lx, lys = ly;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const int cx = lx + dx, cy = ly + dy;
+                    const int cx = lxs + dx, cy = lys + dy;
                     if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
                         atomicAdd(ldsu + cy * wn.ww + cx, fix_u32(ky[dy], kx[dx]));
                     } else {
-                        const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
+                        const int gx = wrap_drop(sx - 1 + dx, g.W), gy = wrap_drop(sy - 1 + dy, g.H);
                         // straight to HBM in the accumulator's own scale (ky carries 2^fshift; a tap * 2^30 fits 32 bits)
                         if (gx >= 0 && gy >= 0)
                             atomicAdd(img + (size_t)gy * g.W + gx, (unsigned long long)fix_u32(ky[dy] * FIX_INV * 1073741824.0f, kx[dx]));
@@ -781,7 +775,6 @@ __device__ __forceinline__ double mse_from_moments(const ImgScal& s, double sE, 
 //   contrast (variance): a_r * (2/HW) * (I - mean I)
 //   correlation:         Gn/D + dm*[I==m]/#min + dM*[I==M]/#max,  Gn = b_r*(2/HW)*(E - n)
 // ------------------------------------------------------------------------------------------------
-constexpr int IMG_TPG = 4;        // tiles per k_imgrad workgroup
 __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
         const float* __restrict__ iwe, const float* __restrict__ edges,
         const StatPart* __restrict__ parts, const WinConst* __restrict__ wc,
@@ -791,39 +784,21 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
         unsigned* __restrict__ gmax)           // (B,R,ntiles): this tile's max |G| as float bits: fixes the fixed-point scale of the
                                                // gradient accumulators (gmax_of, grad_shift)
 {
-    // grid (ceil(ntiles / IMG_TPG), R, B): a workgroup walks IMG_TPG consecutive tiles of one image.  The per-image scalars (a
-    // dependent chain of loads, fp64 wave reductions and divisions: ~3 us) are paid once per workgroup instead of once per tile, the
-    // next tile's pixels are in flight while the current one is processed, and the whole image stack is one round of workgroups.
-    __shared__ double g2w[IMG_TPG][NWAVE];
-    __shared__ float gmw[IMG_TPG][NWAVE];
+    __shared__ double g2scratch[NWAVE];
+    __shared__ float gmscratch[NWAVE];
     constexpr int P2 = TS + 4, P1 = TS + 2;
-    constexpr int NPF = (P2 * P2 + NT - 1) / NT;          // pixels of the haloed tile per thread
-    constexpr int NOWN = TS * TS / NT;                    // own pixels per thread
     __shared__ float t[P2][P2 + 1];
     __shared__ float sgx[P1][P1 + 1], sgy[P1][P1 + 1];   // fp32 stencils: inputs (IWE) and output (G) are fp32 images
-    __shared__ double sc[9];
+    __shared__ double sc[10];
     const bool use_div = (ep.delta != 0.0);
-    const int grp = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
+    const int tile = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
+    const int tx = tile % g.tilesX, ty = tile / g.tilesX;
+    const int x0 = tx * TS, y0 = ty * TS;
     const double HW = (double)g.H * (double)g.W;
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
     const float* __restrict__ E = edges + ((size_t)b * g.R + r) * g.H * g.W;
     float* __restrict__ Go = G + ((size_t)b * g.R + r) * g.H * g.W;
     const WinConst& c = wc[b];
-    const int tile0 = grp * IMG_TPG, ntl = min(IMG_TPG, g.ntiles - tile0);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-
-    float pf[NPF];                                        // the haloed pixels of the NEXT tile, in flight
-    auto prefetch = [&](int tile) {
-        const int x0 = (tile % g.tilesX) * TS, y0 = (tile / g.tilesX) * TS;
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-            const int p = threadIdx.x + k * NT;
-            const int ly = p / P2, lx = p % P2;
-            const int y = y0 + ly - 2, x = x0 + lx - 2;
-            pf[k] = (p < P2 * P2 && y >= 0 && y < g.H && x >= 0 && x < g.W) ? I[(size_t)y * g.W + x] : 0.0f;
-        }
-    };
-    prefetch(tile0);
 
     if (threadIdx.x < 64) {
         const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
@@ -852,86 +827,71 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
             sc[5] = ((sGn_n - sGn) / s.D) / s.cm;            // dm / #argmin
             sc[6] = (-sGn_n / s.D) / s.cM;                   // dM / #argmax
             sc[7] = s.sI / HW;                               // mean I
+            sc[9] = 1.0 / s.D;                               // n = (I - m) * (1/D): one fp64 division per image, not per pixel (<= 1 ulp)
         }
     }
-
-    for (int k = 0; k < ntl; ++k) {
-        const int tile = tile0 + k;
-        const int x0 = (tile % g.tilesX) * TS, y0 = (tile / g.tilesX) * TS;
-        if (k) __syncthreads();                          // the previous tile's stencils have read t / sgx / sgy
-#pragma unroll
-        for (int q = 0; q < NPF; ++q) {
-            const int p = threadIdx.x + q * NT;
-            if (p < P2 * P2) t[p / P2][p % P2] = pf[q];
-        }
-        if (k + 1 < ntl) prefetch(tile + 1);
-        float ev[NOWN];                                  // this thread's edge pixels: in flight during the first stencil
-#pragma unroll
-        for (int q = 0; q < NOWN; ++q) {
-            const int p = threadIdx.x + q * NT;
-            const int y = y0 + p / TS, x = x0 + p % TS;
-            ev[q] = (y < g.H && x < g.W) ? E[(size_t)y * g.W + x] : 0.0f;
-        }
-        __syncthreads();                                 // t complete (and sc, on the first trip)
-        float g2f = 0.0f;
-        if (ep.contrast_kind == 0) {
-            for (int p = threadIdx.x; p < P1 * P1; p += NT) {
-                const int ly = p / P1, lx = p % P1;
-                const int y = y0 + ly - 1, x = x0 + lx - 1;
-                float gx = 0.0f, gy = 0.0f;
-                if (y >= 0 && y < g.H && x >= 0 && x < g.W) {   // zero outside the image
-                    const int cy = ly + 1, cx = lx + 1;
-                    gx = 3.0f * (t[cy + 1][cx + 1] - t[cy + 1][cx - 1]) + 10.0f * (t[cy][cx + 1] - t[cy][cx - 1]) + 3.0f * (t[cy - 1][cx + 1] - t[cy - 1][cx - 1]);
-                    gy = 3.0f * (t[cy + 1][cx + 1] - t[cy - 1][cx + 1]) + 10.0f * (t[cy + 1][cx] - t[cy - 1][cx]) + 3.0f * (t[cy + 1][cx - 1] - t[cy - 1][cx - 1]);
-                }
-                sgx[ly][lx] = gx; sgy[ly][lx] = gy;
-                if (ly >= 1 && ly <= TS && lx >= 1 && lx <= TS) g2f += gx * gx + gy * gy;   // own pixels only (zero outside the image)
-            }
-            __syncthreads();
-        }
-        const double m = sc[0], M = sc[1], D = sc[2];
-        float gm = 0.0f;
-#pragma unroll
-        for (int q = 0; q < NOWN; ++q) {
-            const int p = threadIdx.x + q * NT;
-            const int ly = p / TS, lx = p % TS;
-            const int y = y0 + ly, x = x0 + lx;
-            if (y >= g.H || x >= g.W) continue;
-            const double v = (double)t[ly + 2][lx + 2];
-            double dc;
-            if (ep.contrast_kind == 0) {
-                // adj_Sx(gx) = -conv(gx, Sx), adj_Sy(gy) = -conv(gy, Sy)
-                const int cy = ly + 1, cx = lx + 1;
-                const float ax = 3.0f * (sgx[cy + 1][cx + 1] - sgx[cy + 1][cx - 1]) + 10.0f * (sgx[cy][cx + 1] - sgx[cy][cx - 1])
-                               + 3.0f * (sgx[cy - 1][cx + 1] - sgx[cy - 1][cx - 1]);
-                const float ay = 3.0f * (sgy[cy + 1][cx + 1] - sgy[cy - 1][cx + 1]) + 10.0f * (sgy[cy + 1][cx] - sgy[cy - 1][cx])
-                               + 3.0f * (sgy[cy + 1][cx - 1] - sgy[cy - 1][cx - 1]);
-                dc = -(double)(ax + ay);
-            } else {
-                dc = v - sc[7];
-            }
-            const double n = (v - m) / D;
-            double gv = sc[3] * dc + sc[4] * ((double)ev[q] - n);
-            if (use_div) gv += sc[8] * (double)gdiv[((size_t)b * g.R + r) * g.H * g.W + (size_t)y * g.W + x];
-            if (v == m) gv += sc[5];
-            if (v == M) gv += sc[6];
-            const float gf = (float)gv;
-            Go[(size_t)y * g.W + x] = gf;
-            gm = (gf == gf) ? fmaxf(gm, fabsf(gf)) : INFINITY;
-        }
-        // per-tile by-products: wave partials now, the (fixed-order) sum over the waves after the loop - no barrier per tile
-        double g2 = wave_sum((double)g2f);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_down(gm, o, 64));
-        if (lane == 0) { g2w[k][wv] = g2; gmw[k][wv] = gm; }
+    for (int p = threadIdx.x; p < P2 * P2; p += NT) {
+        const int ly = p / P2, lx = p % P2;
+        const int y = y0 + ly - 2, x = x0 + lx - 2;
+        t[ly][lx] = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? I[(size_t)y * g.W + x] : 0.0f;
     }
     __syncthreads();
-    if ((int)threadIdx.x < ntl) {
-        const int k = threadIdx.x;
-        double g2 = 0.0; float gm = 0.0f;
-        for (int i = 0; i < NWAVE; ++i) { g2 += g2w[k][i]; gm = fmaxf(gm, gmw[k][i]); }
-        g2parts[((size_t)b * g.R + r) * g.ntiles + tile0 + k] = g2;
-        gmax[((size_t)b * g.R + r) * g.ntiles + tile0 + k] = __float_as_uint(gm);
+    double g2 = 0.0;
+    if (ep.contrast_kind == 0) {
+        float g2f = 0.0f;
+        for (int p = threadIdx.x; p < P1 * P1; p += NT) {
+            const int ly = p / P1, lx = p % P1;
+            const int y = y0 + ly - 1, x = x0 + lx - 1;
+            float gx = 0.0f, gy = 0.0f;
+            if (y >= 0 && y < g.H && x >= 0 && x < g.W) {   // zero outside the image
+                const int cy = ly + 1, cx = lx + 1;
+                gx = 3.0f * (t[cy + 1][cx + 1] - t[cy + 1][cx - 1]) + 10.0f * (t[cy][cx + 1] - t[cy][cx - 1]) + 3.0f * (t[cy - 1][cx + 1] - t[cy - 1][cx - 1]);
+                gy = 3.0f * (t[cy + 1][cx + 1] - t[cy - 1][cx + 1]) + 10.0f * (t[cy + 1][cx] - t[cy - 1][cx]) + 3.0f * (t[cy + 1][cx - 1] - t[cy - 1][cx - 1]);
+            }
+            sgx[ly][lx] = gx; sgy[ly][lx] = gy;
+            if (ly >= 1 && ly <= TS && lx >= 1 && lx <= TS) g2f += gx * gx + gy * gy;   // own pixels only (zero outside the image)
+        }
+        g2 = (double)g2f;
+        __syncthreads();
+    }
+    g2 = block_sum(g2, g2scratch);
+    if (threadIdx.x == 0) g2parts[((size_t)b * g.R + r) * g.ntiles + tile] = g2;
+    const double m = sc[0], M = sc[1], invD = sc[9];
+    float gm = 0.0f;
+    for (int p = threadIdx.x; p < TS * TS; p += NT) {
+        const int ly = p / TS, lx = p % TS;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= g.H || x >= g.W) continue;
+        const double v = (double)t[ly + 2][lx + 2];
+        double dc;
+        if (ep.contrast_kind == 0) {
+            // adj_Sx(gx) = -conv(gx, Sx), adj_Sy(gy) = -conv(gy, Sy)
+            const int cy = ly + 1, cx = lx + 1;
+            const float ax = 3.0f * (sgx[cy + 1][cx + 1] - sgx[cy + 1][cx - 1]) + 10.0f * (sgx[cy][cx + 1] - sgx[cy][cx - 1])
+                           + 3.0f * (sgx[cy - 1][cx + 1] - sgx[cy - 1][cx - 1]);
+            const float ay = 3.0f * (sgy[cy + 1][cx + 1] - sgy[cy - 1][cx + 1]) + 10.0f * (sgy[cy + 1][cx] - sgy[cy - 1][cx])
+                           + 3.0f * (sgy[cy + 1][cx - 1] - sgy[cy - 1][cx - 1]);
+            dc = -(double)(ax + ay);
+        } else {
+            dc = v - sc[7];
+        }
+        const double n = (v - m) * invD;
+        const double e = (double)E[(size_t)y * g.W + x];
+        double gv = sc[3] * dc + sc[4] * (e - n);
+        if (use_div) gv += sc[8] * (double)gdiv[((size_t)b * g.R + r) * g.H * g.W + (size_t)y * g.W + x];
+        if (v == m) gv += sc[5];
+        if (v == M) gv += sc[6];
+        const float gf = (float)gv;
+        Go[(size_t)y * g.W + x] = gf;
+        gm = (gf == gf) ? fmaxf(gm, fabsf(gf)) : INFINITY;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_down(gm, o, 64));
+    if ((threadIdx.x & 63) == 0) gmscratch[threadIdx.x >> 6] = gm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < NWAVE; ++i) gm = fmaxf(gm, gmscratch[i]);
+        gmax[((size_t)b * g.R + r) * g.ntiles + tile] = __float_as_uint(gm);
     }
 }
 
@@ -1171,16 +1131,17 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
                 for (int dx = 0; dx < 3; ++dx) gv[dy][dx] = p[dy * wn.ww + dx];
             }
         } else {
+            const int sx = irx, sy = iry, lxs = lx, lys = ly;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const int cx = lx + dx, cy = ly + dy;
+                    const int cx = lxs + dx, cy = lys + dy;
                     float val = 0.0f;
                     if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
                         val = lds[cy * wn.ww + cx];
                     } else {
-                        const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
+                        const int gx = wrap_drop(sx - 1 + dx, g.W), gy = wrap_drop(sy - 1 + dy, g.H);
                         if (gx >= 0 && gy >= 0) val = Gi[(size_t)gy * g.W + gx];
                     }
                     gv[dy][dx] = val;
@@ -1234,170 +1195,6 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
         const int c = i & 1, px = (i >> 1) % TS, py = (i >> 1) / TS;
         const unsigned long long v = accum[i];
         if (px < tw && py < th && v != 0ull) atomicAdd(gT + ((size_t)(y0 + py) * g.W + (x0 + px)) * 2 + c, v);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_gather11: the reverse of the splat for 2-DoF theta (1,1,2), all reference times of a segment in ONE workgroup.
-// grid n_items * nrg (nrg = ceil(R / RF) groups of <= RF reference times; item = blockIdx / nrg after the XCD band mapping).
-// What is shared across the reference times is done once per event instead of R times: the event load, the unpacking, and the
-// fp64 part of the warp.  With a constant velocity v the warped coordinate is  w_r = x - v (t - tau_r) = A + c_r,  A = x - v t
-// (per event, fp64), c_r = v tau_r (per reference time, uniform).  Both are split once into integer and fraction,
-// A = Ai + Af, c_r = ci_r + cf_r, and the per-(event, r) work is fp32 / integer:  s = Af + cf_r in [-1, 1],  rs = rint(s),
-// f = s - rs,  round(w_r) = Ai + ci_r + rs.  That differs from the reference's own operation order by < 2.5e-7 px in f, which is
-// harmless for the taps (fp32 anyway) but could flip a rounding decision when w_r is within that distance of a half-integer:
-// lanes with |f| > 0.5 - 2.5e-7 (about one in 10^6) redo the warp exactly as the reference does (fp64, warp_axis), and so does
-// everything when |v| > 1e5 px / window or v is not finite (A would lose the bits the split relies on).
-// The G windows of the group's reference times sit side by side in LDS (read-only: no LDS atomics in this kernel); the thread's
-// sums are fp32 over its own <= 128 terms, then fp64 in a fixed order (block_sum), stored in the workgroup's own slot.
-// ------------------------------------------------------------------------------------------------
-constexpr int G11_RF = 5;         // reference times per workgroup: 5 x 9 KiB windows -> 3 workgroups per CU
-template <int RF>
-__global__ __launch_bounds__(NT) void k_gather11(Geom g, int n_items, int nrg, int wincap,
-        const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
-        const double* __restrict__ tmm, const double* __restrict__ edge_ts,
-        const float* __restrict__ G,           // (B,R,H,W)
-        double* __restrict__ g11)              // (n_items, nrg, 2) per-workgroup partials of dL/dtheta
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // RF windows of wincap floats
-    __shared__ double red11[NWAVE];
-    // XCD bands: blocks b, b+8, ... share an L2; give each XCD a contiguous eighth of the (window-major) work so that the G images
-    // its workgroups stage stay in that L2
-    const int nblk = n_items * nrg;
-    const int per = (nblk + NXCD - 1) / NXCD;
-    const int work = (blockIdx.x % NXCD) * per + blockIdx.x / NXCD;
-    if (work >= nblk) return;
-    const int item = work / nrg, grp = work % nrg;
-    const int r0 = grp * RF;
-    const Item it = items[item];
-    const double* mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
-    const double vx = mm[0], vy = mm[2];
-    const bool exact_only = !(fabs(vx) <= 1.0e5 && fabs(vy) <= 1.0e5);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-
-    // per reference time (uniform): window, integer / fractional part of c_r = v tau_r, fp32 tau
-    int wox[RF], woy[RF], www[RF], wwh[RF], cix[RF], ciy[RF];
-    float cfx[RF], cfy[RF], tauf[RF];
-    double taud[RF];
-    Geom gw = g; gw.wincap = wincap;
-#pragma unroll
-    for (int k = 0; k < RF; ++k) {
-        const int r = min(r0 + k, g.R - 1);                 // a partial last group repeats the last reference time (its sums are dropped)
-        const double tau = edge_ts[it.win * g.R + r];
-        const Window wn = item_window(gw, it, mm, tau);
-        wox[k] = wn.ox; woy[k] = wn.oy; www[k] = wn.ww; wwh[k] = wn.wh;
-        const double cx = vx * tau, cy = vy * tau;
-        const double rcx = rint(cx), rcy = rint(cy);
-        cix[k] = exact_only ? 0 : (int)rcx; ciy[k] = exact_only ? 0 : (int)rcy;
-        cfx[k] = (float)(cx - rcx); cfy[k] = (float)(cy - rcy);
-        taud[k] = tau; tauf[k] = (float)tau;
-        // stage the G window of this reference time
-        const float* __restrict__ Gi = G + ((size_t)it.win * g.R + r) * g.H * g.W;
-        float* __restrict__ win = lds + k * wincap;
-        if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {
-            const float* __restrict__ src = Gi + (size_t)wn.oy * g.W + wn.ox;
-            for (int row = wv; row < wn.wh; row += NWAVE)
-                for (int col = lane; col < wn.ww; col += 64) win[row * wn.ww + col] = src[row * g.W + col];
-        } else {
-            for (int row = wv; row < wn.wh; row += NWAVE) {
-                const int gy = wrap_drop(wn.oy + row, g.H);
-                for (int col = lane; col < wn.ww; col += 64) {
-                    const int gx = wrap_drop(wn.ox + col, g.W);
-                    win[row * wn.ww + col] = (gx >= 0 && gy >= 0) ? Gi[(size_t)gy * g.W + gx] : 0.0f;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    const uint32_t* __restrict__ exy = ev_xy + it.begin;
-    const double* __restrict__ et = ev_t + it.begin;
-    const int n = it.count;
-    float accx[RF], accy[RF];
-#pragma unroll
-    for (int k = 0; k < RF; ++k) { accx[k] = 0.0f; accy[k] = 0.0f; }
-    constexpr float RISK = 0.5f - 2.5e-7f;
-
-    for (int e = threadIdx.x; e < n; e += NT) {
-        const uint32_t xy = exy[e];
-        const double t = et[e];
-        const int x = xy & 0xffff, y = xy >> 16;
-        // A = x - v t, split into integer and fraction (fp64, once per event)
-        const double Ax = fma(-vx, t, (double)x), Ay = fma(-vy, t, (double)y);
-        const double Arx = rint(Ax), Ary = rint(Ay);
-        const int aix = (int)Arx, aiy = (int)Ary;
-        const float afx = (float)(Ax - Arx), afy = (float)(Ay - Ary);
-        const float tf = (float)t;
-#pragma unroll
-        for (int k = 0; k < RF; ++k) {
-            float sx = afx + cfx[k], sy = afy + cfy[k];
-            const float rsx = rintf(sx), rsy = rintf(sy);
-            float fx = sx - rsx, fy = sy - rsy;
-            int irx = aix + cix[k] + (int)rsx, iry = aiy + ciy[k] + (int)rsy;
-            if (exact_only || fmaxf(fabsf(fx), fabsf(fy)) > RISK) {       // rare: the reference's own operation order decides
-                const double dt = t - taud[k];
-                warp_axis(x, vx, dt, irx, fx);
-                warp_axis(y, vy, dt, iry, fy);
-            }
-            f2v km, k0, kp;
-            taps3x2(fx, fy, INV_2PI, km, k0, kp);
-            // weights of the x- and y-derivative: W[d] = K[d] * ((d - 1) - f)
-            const float wx0 = fmaf(-km.x, fx, -km.x), wx1 = -k0.x * fx, wx2 = fmaf(-kp.x, fx, kp.x);
-            const float wy0 = fmaf(-km.y, fy, -km.y), wy1 = -k0.y * fy, wy2 = fmaf(-kp.y, fy, kp.y);
-            const int lx = irx - 1 - wox[k], ly = iry - 1 - woy[k];
-            float g00, g01, g02, g10, g11v, g12, g20, g21, g22;
-            if ((unsigned)lx < (unsigned)(www[k] - 2) && (unsigned)ly < (unsigned)(wwh[k] - 2)) {
-                const float* p = lds + k * wincap + __mul24(ly, www[k]) + lx;
-                const float* p1 = p + www[k]; const float* p2 = p1 + www[k];
-                g00 = p[0]; g01 = p[1]; g02 = p[2];
-                g10 = p1[0]; g11v = p1[1]; g12 = p1[2];
-                g20 = p2[0]; g21 = p2[1]; g22 = p2[2];
-            } else {                                                       // taps outside the window: straight from HBM, JAX index rule
-                const int r = min(r0 + k, g.R - 1);
-                const float* __restrict__ Gi = G + ((size_t)it.win * g.R + r) * g.H * g.W;
-                const float* win = lds + k * wincap;
-                float gv[3][3];
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const int cx = lx + dx, cy = ly + dy;
-                        float val = 0.0f;
-                        if (cx >= 0 && cy >= 0 && cx < www[k] && cy < wwh[k]) {
-                            val = win[cy * www[k] + cx];
-                        } else {
-                            const int gx = wrap_drop(irx - 1 + dx, g.W), gy = wrap_drop(iry - 1 + dy, g.H);
-                            if (gx >= 0 && gy >= 0) val = Gi[(size_t)gy * g.W + gx];
-                        }
-                        gv[dy][dx] = val;
-                    }
-                }
-                g00 = gv[0][0]; g01 = gv[0][1]; g02 = gv[0][2]; g10 = gv[1][0]; g11v = gv[1][1]; g12 = gv[1][2];
-                g20 = gv[2][0]; g21 = gv[2][1]; g22 = gv[2][2];
-            }
-            // dL/dwx = sum_dx Wx[dx] (sum_dy Ky[dy] G[dy][dx]),  dL/dwy = sum_dx Kx[dx] (sum_dy Wy[dy] G[dy][dx])
-            const float c0 = fmaf(kp.y, g20, fmaf(k0.y, g10, km.y * g00));
-            const float c1 = fmaf(kp.y, g21, fmaf(k0.y, g11v, km.y * g01));
-            const float c2 = fmaf(kp.y, g22, fmaf(k0.y, g12, km.y * g02));
-            const float d0 = fmaf(wy2, g20, fmaf(wy1, g10, wy0 * g00));
-            const float d1 = fmaf(wy2, g21, fmaf(wy1, g11v, wy0 * g01));
-            const float d2 = fmaf(wy2, g22, fmaf(wy1, g12, wy0 * g02));
-            const float gwx = fmaf(wx2, c2, fmaf(wx1, c1, wx0 * c0));
-            const float gwy = fmaf(kp.x, d2, fmaf(k0.x, d1, km.x * d0));
-            const float ndt = tauf[k] - tf;                                 // -(t - tau_r)
-            accx[k] = fmaf(ndt, gwx, accx[k]);
-            accy[k] = fmaf(ndt, gwy, accy[k]);
-        }
-    }
-    double sum11x = 0.0, sum11y = 0.0;
-#pragma unroll
-    for (int k = 0; k < RF; ++k)
-        if (r0 + k < g.R) { sum11x += (double)accx[k]; sum11y += (double)accy[k]; }
-    sum11x = block_sum(sum11x, red11);
-    sum11y = block_sum(sum11y, red11);
-    if (threadIdx.x == 0) {
-        double* dst = g11 + ((size_t)item * nrg + grp) * 2;
-        dst[0] = sum11x; dst[1] = sum11y;
     }
 }
 

@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): kernel trace + stats, then HBM PMC counters in their own passes.
 # Usage: tools/profile_round.sh <tag>      outputs under gpurun_out/prof_<tag>/
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -16,6 +16,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
 echo "pmc write rc=$?"
 rocprofv3 --pmc TCC_EA0_ATOMIC_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_misc -- python3 $ARGS > $OUT/bench_pmc_misc.json 2> $OUT/pmc_misc.err
 echo "pmc misc rc=$?"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_valu -- python3 $ARGS > $OUT/bench_pmc_valu.json 2> $OUT/pmc_valu.err
+echo "pmc valu rc=$?"
 find $OUT -name "*.csv" | head -40
 python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recurs
         print(f"  {short(r['Name'])[:42]:42s} calls {r['Calls']:>6s} total_ns {r['TotalDurationNs']:>12s} avg_ns {float(r['AverageNs']):>12.1f} "
               f"pct {r['Percentage']:>6s}")
 
-for tag in ('pmc_fetch', 'pmc_write', 'pmc_misc'):
+for tag in ('pmc_fetch', 'pmc_write', 'pmc_misc', 'pmc_valu'):
     for f in glob.glob(os.path.join(out, tag, '**', '*counter_collection.csv'), recursive=True):
         acc = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(f)):
