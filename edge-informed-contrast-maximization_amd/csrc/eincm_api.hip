@@ -542,7 +542,7 @@ int eval_end_launch(eincm_ctx* c) {
     {
         StageTimer t(c, EINCM_STAGE_FINAL);
         // small results (everything but a dense gradient) are written by k_final straight into pinned host memory: no D2H copy command
-        hipLaunchKernelGGL(k_final, dim3(g.B), dim3(NT), 0, c->stream, g, ep, c->d_parts, c->d_divparts, c->d_tvparts,
+        hipLaunchKernelGGL(k_final, dim3(g.B), dim3(FT), 0, c->stream, g, ep, c->d_parts, c->d_divparts, c->d_tvparts,
                            c->d_tmm, c->d_wc, g2_from_imgrad ? c->d_g2parts : nullptr, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap,
                            c->d_g11, c->d_win_item0, c->n_items, c->g11_per_item, c->d_gmax,
                            zero_copy_out ? c->h_outs : c->d_outs, zero_copy_out ? c->h_grad : c->d_grad, want_grad ? 1 : 0);

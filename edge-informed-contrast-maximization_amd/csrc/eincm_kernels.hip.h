@@ -198,7 +198,9 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
-// block-wide sum of a double; result valid in thread 0.  scratch: >= NWAVE doubles of LDS.
+// block-wide sum of a double (fixed order: the wave tree, then the waves in index order); result valid in thread 0.
+// scratch: >= NW doubles of LDS; NW = waves in the workgroup.
+template <int NW = NWAVE>
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -208,7 +210,7 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
     double r = 0.0;
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int i = 0; i < NWAVE; ++i) r += scratch[i];
+        for (int i = 0; i < NW; ++i) r += scratch[i];
     }
     return r;
 }
@@ -1502,7 +1504,8 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
 // Also combines the coarse gradient: grad = gth_main + tv_scale * gth_tv (h*w*2 <= a few thousand values);
 // the dense (identity) gradient is combined by k_final_dense.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
+constexpr int FT = 512, FW = FT / 64;      // k_final: 8 waves, so that up to 8 reference times are reduced side by side
+__global__ __launch_bounds__(FT) void k_final(Geom g, EvalParams ep,
         const StatPart* __restrict__ parts, const double* __restrict__ divparts, const double* __restrict__ tvparts,
         const double* __restrict__ tmm, const WinConst* __restrict__ wc,
         const double* __restrict__ g2parts,    // contrast energy partials from k_imgrad, or nullptr (then parts[].sG2 holds it)
@@ -1511,17 +1514,39 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
         const unsigned* __restrict__ gmax,
         OutScal* __restrict__ outs, double* __restrict__ grad_out, int want_grad)
 {
-    __shared__ double scratch[NWAVE];
+    __shared__ double scratch[FW];
     __shared__ double sh_tvscale;
     __shared__ double sh_rel[3][16];           // per reference time: rel_contrast, rel_corr, rel_div terms
     const int b = blockIdx.x;
     const WinConst& c = wc[b];
     OutScal* __restrict__ o = outs + b;
     const double HW = (double)g.H * (double)g.W;
-    // one wave per reference time (waves take r = wave, wave + NWAVE, ...): no block-wide barriers inside the loop
+    // This kernel is a latency chain on 8 workgroups; everything that depends on nothing is loaded first so that the loads overlap
+    // the per-reference-time reductions: the NaN scan of the velocity bounds and the first partials of the 2-DoF gradient.
+    double bad = 0.0;
+    for (int i = threadIdx.x; i < g.ntiles * 4; i += FT) {
+        const double v = tmm[(size_t)b * g.ntiles * 4 + i];
+        if (!(v == v)) bad = 1.0;
+    }
+    const bool grad11 = want_grad && !ep.identity && ep.h * ep.w == 1;
+    double sx11 = 0.0, sy11 = 0.0;
+    if (grad11) {
+        // 2-DoF: add the partials of this window's k_gather workgroups in index order (fixed strided order per thread, then the
+        // fixed tree of block_sum): bit-reproducible without any atomic.  Four loads in flight per trip.
+        const int lo = win_item0[b], hi = (b + 1 < g.B) ? win_item0[b + 1] : n_items;
+        const double2* __restrict__ q = reinterpret_cast<const double2*>(g11);
+        const int kend = hi * g11_per_item;
+        int k = lo * g11_per_item + threadIdx.x;
+        for (; k + 3 * FT < kend; k += 4 * FT) {
+            const double2 a0 = q[k], a1 = q[k + FT], a2 = q[k + 2 * FT], a3 = q[k + 3 * FT];
+            sx11 += (a0.x + a1.x) + (a2.x + a3.x); sy11 += (a0.y + a1.y) + (a2.y + a3.y);
+        }
+        for (; k < kend; k += FT) { const double2 a = q[k]; sx11 += a.x; sy11 += a.y; }
+    }
+    // one wave per reference time (waves take r = wave, wave + FW, ...): no block-wide barriers inside the loop
     {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        for (int r = wv; r < g.R; r += NWAVE) {
+        for (int r = wv; r < g.R; r += FW) {
             double dsum = 0.0, g2sum = 0.0;
             if (ep.want_div) {
                 double v = 0.0;
@@ -1556,21 +1581,16 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
     double tv = 0.0, tvscale = 0.0;
     if (ep.want_tv) {
         double a = 0.0, n = 0.0;
-        for (int i = threadIdx.x; i < g.ntiles; i += NT) {
+        for (int i = threadIdx.x; i < g.ntiles; i += FT) {
             a += tvparts[((size_t)b * g.ntiles + i) * 3];
             n += tvparts[((size_t)b * g.ntiles + i) * 3 + 1];
         }
-        a = block_sum(a, scratch);
-        n = block_sum(n, scratch);
+        a = block_sum<FW>(a, scratch);
+        n = block_sum<FW>(n, scratch);
         if (threadIdx.x == 0) { tv = a / (n + EPSN); tvscale = ep.gamma * 0.25 / (n + EPSN); }
     }
     // a NaN anywhere in theta must surface as a NaN loss (the reference propagates it through the warp)
-    double bad = 0.0;
-    for (int i = threadIdx.x; i < g.ntiles * 4; i += NT) {
-        const double v = tmm[(size_t)b * g.ntiles * 4 + i];
-        if (!(v == v)) bad = 1.0;
-    }
-    bad = block_sum(bad, scratch);
+    bad = block_sum<FW>(bad, scratch);
     if (threadIdx.x == 0) {
         const double R = (double)g.R;
         const double mrc = sum_rel_con / R, mrr = sum_rel_corr / R;
@@ -1595,22 +1615,9 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
         const double s = sh_tvscale * ldexp(1.0, -tv_shift(g.H, g.W));
         const int n = ep.h * ep.w * 2;
         if (n == 2) {
-            // 2-DoF: add the partials of this window's k_gather workgroups in index order (fixed strided order per thread, then
-            // the fixed tree of block_sum): bit-reproducible without any atomic
-            const int lo = win_item0[b], hi = (b + 1 < g.B) ? win_item0[b + 1] : n_items;
-            // (four loads in flight per trip: one workgroup adds ~7500 partials per window, and a loop that waits for every load
-            // pays a memory latency 30 times)
-            const double2* __restrict__ q = reinterpret_cast<const double2*>(g11);
-            const int kend = hi * g11_per_item;
-            double sx = 0.0, sy = 0.0;
-            int k = lo * g11_per_item + threadIdx.x;
-            for (; k + 3 * NT < kend; k += 4 * NT) {
-                const double2 a0 = q[k], a1 = q[k + NT], a2 = q[k + 2 * NT], a3 = q[k + 3 * NT];
-                sx += (a0.x + a1.x) + (a2.x + a3.x); sy += (a0.y + a1.y) + (a2.y + a3.y);
-            }
-            for (; k < kend; k += NT) { const double2 a = q[k]; sx += a.x; sy += a.y; }
-            sx = block_sum(sx, scratch);
-            sy = block_sum(sy, scratch);
+            double sx = sx11, sy = sy11;
+            sx = block_sum<FW>(sx, scratch);
+            sy = block_sum<FW>(sy, scratch);
             if (threadIdx.x == 0) {
                 if (ep.use_tv_grad) {
                     sx += s * (double)gth_tv[(size_t)b * gth_cap]; sy += s * (double)gth_tv[(size_t)b * gth_cap + 1];
@@ -1619,9 +1626,9 @@ __global__ __launch_bounds__(NT) void k_final(Geom g, EvalParams ep,
                 grad_out[(size_t)b * 2] = sx; grad_out[(size_t)b * 2 + 1] = sy;
             }
         } else {
-            __shared__ unsigned gms[NWAVE];
+            __shared__ unsigned gms[FW];
             const double inv = ldexp(1.0, -grad_shift(c, gmax_of(gmax + (size_t)b * g.R * g.ntiles, g.R * g.ntiles, gms), g.R));
-            for (int i = threadIdx.x; i < n; i += NT) {
+            for (int i = threadIdx.x; i < n; i += FT) {
                 double v = (double)gth_main[(size_t)b * gth_cap + i] * inv;
                 gth_main[(size_t)b * gth_cap + i] = 0;
                 if (ep.use_tv_grad) { v += s * (double)gth_tv[(size_t)b * gth_cap + i]; gth_tv[(size_t)b * gth_cap + i] = 0; }

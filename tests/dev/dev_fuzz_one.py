@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """dev: run one fuzz case (index in the test's sequence) with a given library and print where the gradient differs."""
 import importlib, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests', 'dev'))
 import numpy as np
 L = importlib.import_module('edge-informed-contrast-maximization_amd._lib')
