@@ -84,14 +84,14 @@ struct eincm_ctx {
     double* d_g11 = nullptr;       // (max_items, R, 2) 2-DoF theta: per-workgroup partials of dL/dtheta (k_gather -> k_final)
     int32_t* d_win_item0 = nullptr;// (B) first segment of each window in d_items
     double* d_dtmax = nullptr;     // (B) staging scratch: max |t - tau| per window
-    unsigned* d_gmax = nullptr;    // (B,R,ntiles) per-tile max |dL/dIWE| as float bits (scale of the i64 gradient accumulators)
+    unsigned* d_gmax = nullptr;    // (B,R,nig) per-strip max |dL/dIWE| as float bits (scale of the i64 gradient accumulators)
     unsigned* d_cntmax = nullptr;  // (B) staging scratch: most events on one source pixel
     double* d_tvg = nullptr;       // (B,H,W,2)
     uint8_t* d_mask = nullptr;     // (B,H,W)
     double* d_tmm = nullptr;       // (B,ntiles,4)
     StatPart* d_parts = nullptr;   // (B,R,ntiles)
     double* d_divparts = nullptr;  // (B,R,ntiles)
-    double* d_g2parts = nullptr;   // (B,R,ntiles) contrast energy partials written by k_imgrad
+    double* d_g2parts = nullptr;   // (B,R,nig) contrast energy partials written by k_imgrad
     float* d_gdiv = nullptr;       // (B,R,H,W) divergence adjoint image, allocated on first delta != 0 gradient
     double* d_dgparts = nullptr;   // (B,R,ntiles,2)
     double* d_tvparts = nullptr;   // (B,ntiles,3)
@@ -508,7 +508,7 @@ int eval_end_launch(eincm_ctx* c) {
             if (div_grad)
                 hipLaunchKernelGGL(k_divgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_parts,
                                    c->d_gdiv, c->d_dgparts);
-            hipLaunchKernelGGL(k_imgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, ep, c->d_iwe, c->d_edges,
+            hipLaunchKernelGGL(k_imgrad, dim3((g.nig + IG_NT / 64 - 1) / (IG_NT / 64), g.R, g.B), dim3(IG_NT), 0, c->stream, g, ep, c->d_iwe, c->d_edges,
                                c->d_parts, c->d_wc, c->d_gdiv, c->d_dgparts, c->d_g2parts, c->d_G, c->d_gmax);
         }
         {
@@ -759,8 +759,9 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_win_item0, B + 1));
     TRY(dalloc(&c->d_dtmax, B));
     TRY(dalloc(&c->d_cntmax, B));
-    TRY(dalloc(&c->d_gmax, B * R * ntiles));
-    TRY(hipMemset(c->d_gmax, 0, B * R * ntiles * sizeof(unsigned)));
+    const size_t nig = (size_t)((W + IG_COLS - 1) / IG_COLS) * ((H + IG_ROWS - 1) / IG_ROWS);   // k_imgrad strips per image
+    TRY(dalloc(&c->d_gmax, B * R * nig));
+    TRY(hipMemset(c->d_gmax, 0, B * R * nig * sizeof(unsigned)));
     TRY(dalloc(&c->d_zero_iwe, B * img));
     TRY(dalloc(&c->d_Theta, B * img * 2));
     TRY(dalloc(&c->d_theta_in, B * img * 2));
@@ -771,7 +772,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_tmm, B * ntiles * 4));
     TRY(dalloc(&c->d_parts, B * R * ntiles));
     TRY(dalloc(&c->d_divparts, B * R * ntiles));
-    TRY(dalloc(&c->d_g2parts, B * R * ntiles));
+    TRY(dalloc(&c->d_g2parts, B * R * nig));
     TRY(dalloc(&c->d_tvparts, B * ntiles * 3));
     TRY(dalloc(&c->d_wc, B));
     {   // one device block and one pinned block: [OutScal x B | grad (B,H,W,2)] -> a single D2H copy per evaluation
@@ -827,6 +828,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     Geom g{};
     g.H = H; g.W = W; g.R = n_refs; g.B = n_windows;
     g.tilesX = (W + TS - 1) / TS; g.tilesY = (H + TS - 1) / TS; g.ntiles = g.tilesX * g.tilesY;
+    g.igx = (W + IG_COLS - 1) / IG_COLS; g.nig = g.igx * ((H + IG_ROWS - 1) / IG_ROWS);
     g.wincap = c->wincap; g.winmaxw = std::max(40, (int)std::lround(std::sqrt((double)c->wincap * 1.4)));
 
     // Segment lengths (events per workgroup and reference time).  Measured on MI355X (tools/dev_tune.sh, tools/dev_tune1.py):

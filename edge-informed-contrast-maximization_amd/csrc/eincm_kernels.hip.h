@@ -64,6 +64,7 @@ struct Geom {
     int tilesX, tilesY, ntiles;
     int wincap, winmaxw;      // LDS destination-window capacity (pixels) and maximum width of the event kernels
     int nparts;               // StatParts per image written by the statistics kernel of this evaluation (ntiles or NSPART)
+    int igx, nig;             // k_imgrad strips per image row / per image (IG_COLS x IG_ROWS pixels each): slots of g2parts and gmax
 };
 
 struct Item {                     // one segment of event work: <= seg events of one source tile of one window
@@ -772,35 +773,51 @@ __device__ __forceinline__ double mse_from_moments(const ImgScal& s, double sE, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_imgrad: G = dL/dIWE.  grid (ntiles, R, B).
+// k_imgrad: G = dL/dIWE.  grid (ceil(nig / 4), R, B), 4 waves per workgroup, one strip of IG_COLS x IG_ROWS pixels per wave.
 //   contrast (grad-mag): a_r * (2/HW) * (adj_Sx(gx) + adj_Sy(gy)),  adj_S(c) = -conv_same(c, S) for Scharr
 //   contrast (variance): a_r * (2/HW) * (I - mean I)
 //   correlation:         Gn/D + dm*[I==m]/#min + dM*[I==M]/#max,  Gn = b_r*(2/HW)*(E - n)
+// The two stacked 3x3 stencils run as a sliding window over rows held in registers: a lane owns one image column, its
+// horizontal neighbours come from the adjacent lanes by DPP wave shifts (no LDS), its vertical neighbours from the
+// previous iterations.  Lanes 0,1,62,63 and rows -2,-1,+1,+2 of a strip are halo (5x5 support of the stacked stencils).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
+constexpr int IG_ROWS = 16, IG_COLS = 60, IG_NT = 256;
+
+template <int CTRL> __device__ __forceinline__ float dpp_lane(float v) {       // zero where the source lane does not exist
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_m1(float v) { return dpp_lane<0x138>(v); }   // wave_shr:1 -> value of lane - 1
+__device__ __forceinline__ float lane_p1(float v) { return dpp_lane<0x130>(v); }   // wave_shl:1 -> value of lane + 1
+
+__global__ __launch_bounds__(IG_NT) void k_imgrad(Geom g, EvalParams ep,
         const float* __restrict__ iwe, const float* __restrict__ edges,
         const StatPart* __restrict__ parts, const WinConst* __restrict__ wc,
         const float* __restrict__ gdiv, const double* __restrict__ dgparts,    // delta != 0 only (else unused)
-        double* __restrict__ g2parts,          // (B,R,ntiles): this tile's sum of gx^2+gy^2 (contrast energy), a by-product
+        double* __restrict__ g2parts,          // (B,R,nig): this strip's sum of gx^2+gy^2 (contrast energy), a by-product
         float* __restrict__ G,
-        unsigned* __restrict__ gmax)           // (B,R,ntiles): this tile's max |G| as float bits: fixes the fixed-point scale of the
+        unsigned* __restrict__ gmax)           // (B,R,nig): this strip's max |G| as float bits: fixes the fixed-point scale of the
                                                // gradient accumulators (gmax_of, grad_shift)
 {
-    __shared__ double g2scratch[NWAVE];
-    __shared__ float gmscratch[NWAVE];
-    constexpr int P2 = TS + 4, P1 = TS + 2;
-    __shared__ float t[P2][P2 + 1];
-    __shared__ float sgx[P1][P1 + 1], sgy[P1][P1 + 1];   // fp32 stencils: inputs (IWE) and output (G) are fp32 images
     __shared__ double sc[10];
     const bool use_div = (ep.delta != 0.0);
-    const int tile = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
-    const int tx = tile % g.tilesX, ty = tile / g.tilesX;
-    const int x0 = tx * TS, y0 = ty * TS;
+    const int r = blockIdx.y, b = blockIdx.z, lane = threadIdx.x & 63;
+    const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * (IG_NT / 64) + (threadIdx.x >> 6));   // wave-uniform: row tests stay scalar
     const double HW = (double)g.H * (double)g.W;
-    const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
-    const float* __restrict__ E = edges + ((size_t)b * g.R + r) * g.H * g.W;
-    float* __restrict__ Go = G + ((size_t)b * g.R + r) * g.H * g.W;
+    const size_t img = ((size_t)b * g.R + r) * g.H * g.W;
+    const float* __restrict__ I = iwe + img;
+    const float* __restrict__ E = edges + img;
+    float* __restrict__ Go = G + img;
     const WinConst& c = wc[b];
+    const int cx0 = (strip % g.igx) * IG_COLS, cy0 = (strip / g.igx) * IG_ROWS;
+    const int x = cx0 - 2 + lane;
+    // every row of the strip is requested up front from clamped (always valid) addresses, so that the loads are unconditional and
+    // all in flight together (and behind the scalar prologue); padding is applied by selects afterwards
+    const int xc = min(max(x, 0), g.W - 1);
+    float trow[IG_ROWS + 4], erow[IG_ROWS];
+#pragma unroll
+    for (int k = 0; k < IG_ROWS + 4; ++k) trow[k] = I[(size_t)min(max(cy0 - 2 + k, 0), g.H - 1) * g.W + xc];
+#pragma unroll
+    for (int k = 0; k < IG_ROWS; ++k) erow[k] = E[(size_t)min(cy0 + k, g.H - 1) * g.W + xc];
 
     if (threadIdx.x < 64) {
         const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
@@ -832,68 +849,61 @@ __global__ __launch_bounds__(NT) void k_imgrad(Geom g, EvalParams ep,
             sc[9] = 1.0 / s.D;                               // n = (I - m) * (1/D): one fp64 division per image, not per pixel (<= 1 ulp)
         }
     }
-    for (int p = threadIdx.x; p < P2 * P2; p += NT) {
-        const int ly = p / P2, lx = p % P2;
-        const int y = y0 + ly - 2, x = x0 + lx - 2;
-        t[ly][lx] = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? I[(size_t)y * g.W + x] : 0.0f;
-    }
     __syncthreads();
-    double g2 = 0.0;
-    if (ep.contrast_kind == 0) {
-        float g2f = 0.0f;
-        for (int p = threadIdx.x; p < P1 * P1; p += NT) {
-            const int ly = p / P1, lx = p % P1;
-            const int y = y0 + ly - 1, x = x0 + lx - 1;
-            float gx = 0.0f, gy = 0.0f;
-            if (y >= 0 && y < g.H && x >= 0 && x < g.W) {   // zero outside the image
-                const int cy = ly + 1, cx = lx + 1;
-                gx = 3.0f * (t[cy + 1][cx + 1] - t[cy + 1][cx - 1]) + 10.0f * (t[cy][cx + 1] - t[cy][cx - 1]) + 3.0f * (t[cy - 1][cx + 1] - t[cy - 1][cx - 1]);
-                gy = 3.0f * (t[cy + 1][cx + 1] - t[cy - 1][cx + 1]) + 10.0f * (t[cy + 1][cx] - t[cy - 1][cx]) + 3.0f * (t[cy + 1][cx - 1] - t[cy - 1][cx - 1]);
-            }
-            sgx[ly][lx] = gx; sgy[ly][lx] = gy;
-            if (ly >= 1 && ly <= TS && lx >= 1 && lx <= TS) g2f += gx * gx + gy * gy;   // own pixels only (zero outside the image)
-        }
-        g2 = (double)g2f;
-        __syncthreads();
-    }
-    g2 = block_sum(g2, g2scratch);
-    if (threadIdx.x == 0) g2parts[((size_t)b * g.R + r) * g.ntiles + tile] = g2;
-    const double m = sc[0], M = sc[1], invD = sc[9];
-    float gm = 0.0f;
-    for (int p = threadIdx.x; p < TS * TS; p += NT) {
-        const int ly = p / TS, lx = p % TS;
-        const int y = y0 + ly, x = x0 + lx;
-        if (y >= g.H || x >= g.W) continue;
-        const double v = (double)t[ly + 2][lx + 2];
-        double dc;
-        if (ep.contrast_kind == 0) {
-            // adj_Sx(gx) = -conv(gx, Sx), adj_Sy(gy) = -conv(gy, Sy)
-            const int cy = ly + 1, cx = lx + 1;
-            const float ax = 3.0f * (sgx[cy + 1][cx + 1] - sgx[cy + 1][cx - 1]) + 10.0f * (sgx[cy][cx + 1] - sgx[cy][cx - 1])
-                           + 3.0f * (sgx[cy - 1][cx + 1] - sgx[cy - 1][cx - 1]);
-            const float ay = 3.0f * (sgy[cy + 1][cx + 1] - sgy[cy - 1][cx + 1]) + 10.0f * (sgy[cy + 1][cx] - sgy[cy - 1][cx])
-                           + 3.0f * (sgy[cy + 1][cx - 1] - sgy[cy - 1][cx - 1]);
-            dc = -(double)(ax + ay);
-        } else {
-            dc = v - sc[7];
-        }
-        const double n = (v - m) * invD;
-        const double e = (double)E[(size_t)y * g.W + x];
-        double gv = sc[3] * dc + sc[4] * (e - n);
-        if (use_div) gv += sc[8] * (double)gdiv[((size_t)b * g.R + r) * g.H * g.W + (size_t)y * g.W + x];
-        if (v == m) gv += sc[5];
-        if (v == M) gv += sc[6];
-        const float gf = (float)gv;
-        Go[(size_t)y * g.W + x] = gf;
-        gm = (gf == gf) ? fmaxf(gm, fabsf(gf)) : INFINITY;
-    }
+    if (strip >= g.nig) return;                              // wave-uniform
+    const bool col_in = (x >= 0 && x < g.W);
+    const bool own = col_in && lane >= 2 && lane < 2 + IG_COLS;
+    const int yend = min(cy0 + IG_ROWS, g.H);                // own rows [cy0, yend)
+    const bool gradmag = (ep.contrast_kind == 0);
+    const double m = sc[0], M = sc[1], invD = sc[9], k_c = sc[3], k_n = sc[4], k_m = sc[5], k_M = sc[6], meanI = sc[7], k_d = sc[8];
+
+    // rolling state at iteration i (image row i is loaded): tA,tB = I rows i-2,i-1; dA,dB = horizontal differences of rows i-2,i-1;
+    // gyA,gyB = gy rows i-3,i-2; qA,qB = horizontal differences of gx rows i-3,i-2.  Row i-1 of (gx,gy) and row i-2 of G come out.
+    float tA = 0.f, tB = 0.f, dA = 0.f, dB = 0.f, gyA = 0.f, gyB = 0.f, qA = 0.f, qB = 0.f;
+    float g2f = 0.f;
+    unsigned gm = 0u;                                        // max |G| as bits (non-negative floats order like their patterns; NaN > Inf)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_down(gm, o, 64));
-    if ((threadIdx.x & 63) == 0) gmscratch[threadIdx.x >> 6] = gm;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < NWAVE; ++i) gm = fmaxf(gm, gmscratch[i]);
-        gmax[((size_t)b * g.R + r) * g.ntiles + tile] = __float_as_uint(gm);
+    for (int k = 0; k < IG_ROWS + 4; ++k) {
+        const int i = cy0 - 2 + k;
+        const float tC = (i >= 0 && i < g.H && col_in) ? trow[k] : 0.0f;     // zero padding (losses.py Scharr 'same')
+        float ax = 0.f, ay = 0.f, dC = 0.f, gy = 0.f, qC = 0.f;
+        if (gradmag) {                                       // uniform: the DPP moves below always run with every lane enabled
+            dC = lane_p1(tC) - lane_m1(tC);
+            float gx = 3.0f * dC + 10.0f * dB + 3.0f * dA;
+            const float e = tC - tA;
+            gy = 3.0f * lane_p1(e) + 10.0f * e + 3.0f * lane_m1(e);
+            const bool in1 = (i - 1 >= 0 && i - 1 < g.H) && col_in;          // (gx, gy) are zero outside the image
+            gx = in1 ? gx : 0.0f; gy = in1 ? gy : 0.0f;
+            const bool own1 = own && (i - 1 >= cy0 && i - 1 < yend);
+            g2f += own1 ? (gx * gx + gy * gy) : 0.0f;
+            // adj_Sx(gx) = -conv(gx, Sx), adj_Sy(gy) = -conv(gy, Sy)
+            qC = lane_p1(gx) - lane_m1(gx);
+            ax = 3.0f * qC + 10.0f * qB + 3.0f * qA;
+            const float eg = gy - gyA;
+            ay = 3.0f * lane_p1(eg) + 10.0f * eg + 3.0f * lane_m1(eg);
+        }
+        const int o = i - 2;
+        if (o >= cy0 && o < yend && own) {
+            const double v = (double)tA;
+            const double dc = gradmag ? -(double)(ax + ay) : v - meanI;
+            const double n = (v - m) * invD;
+            const double e = (double)erow[k >= 4 ? k - 4 : 0];
+            double gv = k_c * dc + k_n * (e - n);
+            if (use_div) gv += k_d * (double)gdiv[img + (size_t)o * g.W + x];
+            if (v == m) gv += k_m;
+            if (v == M) gv += k_M;
+            const float gf = (float)gv;
+            Go[(size_t)o * g.W + x] = gf;
+            gm = max(gm, __float_as_uint(gf) & 0x7fffffffu);
+        }
+        tA = tB; tB = tC; dA = dB; dB = dC; gyA = gyB; gyB = gy; qA = qB; qB = qC;
+    }
+    const double g2 = wave_sum((double)g2f);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gm = max(gm, (unsigned)__shfl_down((int)gm, o, 64));
+    if (lane == 0) {
+        g2parts[((size_t)b * g.R + r) * g.nig + strip] = g2;
+        gmax[((size_t)b * g.R + r) * g.nig + strip] = gm;
     }
 }
 
@@ -1092,7 +1102,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
     if (!direct11) {
         __shared__ unsigned gms[NWAVE];
         for (int i = threadIdx.x; i < TS * TS * 2; i += NT) accum[i] = 0ull;
-        gscale = ldexp(1.0, grad_shift_pixel(wc[it.win], gmax_of(gmax + (size_t)it.win * g.R * g.ntiles, g.R * g.ntiles, gms), g.R, WIDE != 0));
+        gscale = ldexp(1.0, grad_shift_pixel(wc[it.win], gmax_of(gmax + (size_t)it.win * g.R * g.nig, g.R * g.nig, gms), g.R, WIDE != 0));
     }
     const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
@@ -1441,7 +1451,7 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
     // src 0: integers at the fine per-pixel scale -> the coarser cell scale (one rounding per pixel and weight).
     // src 1: fp64 TV gradient image -> fixed point at tv_shift.
     __shared__ unsigned gms[NWAVE];
-    const double gm = gmax_of(gmax + (size_t)b * g.R * g.ntiles, g.R * g.ntiles, gms);
+    const double gm = gmax_of(gmax + (size_t)b * g.R * g.nig, g.R * g.nig, gms);
     const double scale = (src == 0) ? ldexp(1.0, grad_shift(wc[b], gm, g.R) - grad_shift_pixel(wc[b], gm, g.R, wide != 0))
                                     : ldexp(1.0, tv_shift(g.H, g.W));
     const bool use_lds = (ncell > 1 && ncell <= PROJ_CELLS);
@@ -1555,7 +1565,7 @@ __global__ __launch_bounds__(FT) void k_final(Geom g, EvalParams ep,
             }
             if (g2parts) {
                 double v = 0.0;
-                for (int i = lane; i < g.ntiles; i += 64) v += g2parts[((size_t)b * g.R + r) * g.ntiles + i];
+                for (int i = lane; i < g.nig; i += 64) v += g2parts[((size_t)b * g.R + r) * g.nig + i];
                 g2sum = __shfl(wave_sum(v), 0, 64);
             }
             const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
@@ -1627,7 +1637,7 @@ __global__ __launch_bounds__(FT) void k_final(Geom g, EvalParams ep,
             }
         } else {
             __shared__ unsigned gms[FW];
-            const double inv = ldexp(1.0, -grad_shift(c, gmax_of(gmax + (size_t)b * g.R * g.ntiles, g.R * g.ntiles, gms), g.R));
+            const double inv = ldexp(1.0, -grad_shift(c, gmax_of(gmax + (size_t)b * g.R * g.nig, g.R * g.nig, gms), g.R));
             for (int i = threadIdx.x; i < n; i += FT) {
                 double v = (double)gth_main[(size_t)b * gth_cap + i] * inv;
                 gth_main[(size_t)b * gth_cap + i] = 0;
@@ -1647,7 +1657,7 @@ __global__ void k_final_dense(Geom g, int use_tv, int wide, long long* __restric
     const size_t n = (size_t)g.H * g.W * 2;
     const double s = outs[b].tv_scale;
     __shared__ unsigned gms[NWAVE];
-    const double inv = ldexp(1.0, -grad_shift_pixel(wc[b], gmax_of(gmax + (size_t)b * g.R * g.ntiles, g.R * g.ntiles, gms), g.R, wide != 0));
+    const double inv = ldexp(1.0, -grad_shift_pixel(wc[b], gmax_of(gmax + (size_t)b * g.R * g.nig, g.R * g.nig, gms), g.R, wide != 0));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const long long q = gTheta[b * n + i];
         if (q != 0) gTheta[b * n + i] = 0;
