@@ -57,6 +57,9 @@ struct eincm_ctx {
     double* d_t = nullptr;         // (maxN)
     Item* d_items = nullptr;       // (max_items) segments walked by k_gather / k_count / k_mask
     Item* d_items_s = nullptr;     // (max_items) shorter segments walked by k_splat
+    int32_t* d_order = nullptr;    // (max_items) d_items by decreasing length: the order the event kernels' workgroups take them in
+    int32_t* d_order_s = nullptr;  // the same for d_items_s
+    std::vector<int32_t> h_order, h_order_s, h_tilecount;   // host sides of the two (kept until the upload has completed)
     Window* d_wins = nullptr;      // (max_items, maxR) destination windows of the gather segments under the current theta
     Window* d_wins_s = nullptr;    // (max_items, maxR) ... of the splat segments
     int n_items_s = 0; int seg_s = 0; int seg_s_used = 0;
@@ -217,7 +220,7 @@ void multi_ref_weights(int R, double* w) {
 
 void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_items_s); F(c->d_wins); F(c->d_wins_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
+    F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_items_s); F(c->d_order); F(c->d_order_s); F(c->d_wins); F(c->d_wins_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
     F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_acc); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
     F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax); F(c->d_cntmax);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
@@ -284,6 +287,25 @@ int ensure_resample(eincm_ctx* c, int h, int w, int method) {
 }
 
 constexpr size_t ZERO_COPY_MAX = 16384;   // doubles of theta / gradient that cross PCIe by zero-copy access to pinned host memory
+
+// The event kernels' workgroups take the segments by decreasing length (block_to_work): stable counting sort of the lengths.
+void order_by_length(const std::vector<int32_t>& lens, std::vector<int32_t>& order) {
+    int32_t maxlen = 0;
+    for (int32_t l : lens) maxlen = std::max(maxlen, l);
+    std::vector<int32_t> start((size_t)maxlen + 2, 0);
+    for (int32_t l : lens) ++start[(size_t)(maxlen - l) + 1];
+    for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
+    order.resize(lens.size());
+    for (size_t i = 0; i < lens.size(); ++i) order[(size_t)start[(size_t)(maxlen - lens[i])]++] = (int32_t)i;
+}
+// segment lengths of a (window, tile) population list, in the order k_items emits the segments
+void segment_lengths(const std::vector<int32_t>& tilecount, int seg, std::vector<int32_t>& lens) {
+    lens.clear();
+    for (int32_t cnt : tilecount) {
+        const int len = balanced_seg_len(cnt, seg);
+        for (int s0 = 0; s0 < cnt; s0 += len) lens.push_back(std::min(len, cnt - s0));
+    }
+}
 
 // blocks of the two event kernels: every (segment, reference time) pair, padded to a multiple of 8 segments (block_to_work)
 unsigned event_grid(const eincm_ctx* c) { return (unsigned)(((c->n_items + NXCD - 1) / NXCD) * NXCD * c->g.R); }
@@ -354,7 +376,7 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
             const size_t lds_bytes = (size_t)(lds_multi ? 2 : 1) * g.wincap * sizeof(float)
                                    + (theta_mode == THETA_TILE ? TS * TS * sizeof(double2) : 0);
 #define SPLAT_ARGS dim3(splat_grid(c)), dim3(NT), lds_bytes, c->stream, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
-                   c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wins_s, c->d_acc
+                   c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wins_s, c->d_acc, c->d_order_s
             if (lds_multi)                      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<0, 1>), SPLAT_ARGS);      // long segments (EINCM_SEG_SPLAT > EINCM_CHUNK)
             else if (theta_mode == THETA_CONST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_CONST, 0>), SPLAT_ARGS);
             else                                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_TILE, 0>), SPLAT_ARGS);
@@ -517,7 +539,7 @@ int eval_end_launch(eincm_ctx* c) {
 #define GATHER_ARGS dim3(event_grid(c)), dim3(NT), \
                     g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), c->stream, \
                     g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_wins, c->d_gTheta, \
-                    direct11 ? 1 : 0, c->d_g11, c->d_wc, c->d_gmax, direct11 ? THETA_CONST : THETA_TILE
+                    direct11 ? 1 : 0, c->d_g11, c->d_wc, c->d_gmax, direct11 ? THETA_CONST : THETA_TILE, c->d_order
                 if (direct11) {
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_CONST, 0>), GATHER_ARGS);
                     c->g11_per_item = g.R;
@@ -731,6 +753,8 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_t, (size_t)max_events_total));
     TRY(dalloc(&c->d_items, (size_t)c->max_items));
     TRY(dalloc(&c->d_items_s, (size_t)c->max_items));
+    TRY(dalloc(&c->d_order, (size_t)c->max_items));
+    TRY(dalloc(&c->d_order_s, (size_t)c->max_items));
     TRY(dalloc(&c->d_wins, (size_t)c->max_items * max_refs));
     TRY(dalloc(&c->d_wins_s, (size_t)c->max_items * max_refs));
     c->host_binning = (ntiles > BIN_MAX_TILES) || (getenv("EINCM_HOST_BINNING") != nullptr);
@@ -831,20 +855,18 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     g.igx = (W + IG_COLS - 1) / IG_COLS; g.nig = g.igx * ((H + IG_ROWS - 1) / IG_ROWS);
     g.wincap = c->wincap; g.winmaxw = std::max(40, (int)std::lround(std::sqrt((double)c->wincap * 1.4)));
 
-    // Segment lengths (events per workgroup and reference time).  Measured on MI355X (tools/dev_tune.sh, tools/dev_tune1.py):
-    // per-workgroup fixed cost (window clear / flush, G-window load, reductions) dominates short segments at every batch size,
-    // so segments are long even when that leaves < 1 workgroup per CU; k_splat, bound by LDS atomics, prefers somewhat
-    // shorter ones (more, smaller windows) than k_gather, which pays a G-window load per segment.
-    int seg = c->seg > 0 ? c->seg : 8192;
-    // a small batch (one or two windows) would give k_gather less than one round of workgroups (2048 resident); then shorter,
-    // more numerous segments finish sooner: 100.9 -> 97.4 us for one 10^6-event window, while the 8-window batch prefers 8192
-    if (c->seg <= 0 && ((double)N / 8192.0 + 0.5 * n_windows * g.ntiles) * n_refs < 2048.0) seg = 4096;
+    // Segment lengths (events per workgroup and reference time), measured on MI355X with the longest-first order of block_to_work
+    // (tools/dev_tune_seg.py, profiles/r02/segment_tuning.txt).  Per-workgroup fixed cost (window clear / flush, G-window load,
+    // reductions) favours long segments, the end of the launch (the last workgroups run on a mostly idle chip) short ones; x
+    // estimates the workgroups of a launch at 8192-event segments against the 2048 the chip holds at once.
+    //   k_gather: x >= 4000 (8 windows x 10^6 events, one window of 10^7): 16384 (96.9 -> 91.7 us, 167 -> 140 us);
+    //             x < 1000 (one 10^6-event window): 4096 (22.8 us against 25.5 with 8192 and 41 with 16384); else 8192.
+    //   k_splat:  bound by LDS atomics, it gains nothing beyond 8192 (108 us at 8192 and 16384, 122 at 4096, 186 at 2048 on the
+    //             8-window batch); 4096 only where the launch would not fill the chip.
+    const double x_wg = ((double)N / 8192.0 + 0.5 * n_windows * g.ntiles) * n_refs;
+    int seg = c->seg > 0 ? c->seg : (x_wg >= 4000.0 ? 16384 : (x_wg < 1000.0 ? 4096 : 8192));
     c->seg_used = seg;
-    // k_splat: 4096-event segments unless the batch is large enough to fill the chip twice over with 8192-event ones; the longer
-    // segments halve the number of window flushes (u64 atomics), which is what the exact accumulator costs: measured 115 -> 112 us
-    // on the 8-window batch, while a single 10^6-event window is faster with 4096 (more workgroups than slots matters more there)
-    int seg_s = c->seg_s > 0 ? c->seg_s : 4096;
-    if (c->seg_s <= 0 && ((double)N / 8192.0 + 0.5 * n_windows * g.ntiles) * n_refs >= 4096.0) seg_s = 8192;
+    int seg_s = c->seg_s > 0 ? c->seg_s : (x_wg >= 1000.0 ? 8192 : 4096);
     c->seg_s_used = seg_s;
     if (!c->chunk_fixed) c->chunk = std::max(4096, std::min(seg_s, MAX_CHUNK));     // single-chunk segments: no f32 commit pass
     const size_t img = (size_t)H * W;
@@ -898,6 +920,8 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         std::vector<double> mom((size_t)n_windows * n_refs * EDGE_PARTS * 2);
         HIPCHK(c, hipMemcpyAsync(misc, c->d_bin_misc, sizeof misc, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(mom.data(), c->d_edge_moments, mom.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        c->h_tilecount.resize((size_t)M);
+        HIPCHK(c, hipMemcpyAsync(c->h_tilecount.data(), c->d_tilecount, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (misc[2] != 0x7fffffff) {
             const int64_t e = misc[2];
@@ -941,6 +965,19 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             if (n_items_s_total > 0)
                 hipLaunchKernelGGL(k_seg_minmax, dim3(std::min(n_items_s_total, 4096)), dim3(NT), 0, c->stream, n_items_s_total, c->d_items_s, c->d_t);
             HIPCHK(c, hipGetLastError());
+            {   // longest-first order of both segment lists, from the tile populations (the host repeats k_items' arithmetic)
+                std::vector<int32_t> lens;
+                segment_lengths(c->h_tilecount, seg, lens);
+                if ((int)lens.size() != n_items_total) return fail(c, EINCM_ERR_ARG, "internal: segment lists disagree (%zu, %d)", lens.size(), n_items_total);
+                order_by_length(lens, c->h_order);
+                segment_lengths(c->h_tilecount, seg_s, lens);
+                if ((int)lens.size() != n_items_s_total) return fail(c, EINCM_ERR_ARG, "internal: splat segment lists disagree (%zu, %d)", lens.size(), n_items_s_total);
+                order_by_length(lens, c->h_order_s);
+                if (n_items_total > 0)
+                    HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order.data(), c->h_order.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                if (n_items_s_total > 0)
+                    HIPCHK(c, hipMemcpyAsync(c->d_order_s, c->h_order_s.data(), c->h_order_s.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            }
         } else {
             HIPCHK(c, hipMemsetAsync(c->d_win_item0, 0, (size_t)(n_windows + 1) * sizeof(int32_t), c->stream));
         }
@@ -1017,6 +1054,18 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         HIPCHK(c, hipMemcpyAsync(c->d_items, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
     if (!items_s.empty())
         HIPCHK(c, hipMemcpyAsync(c->d_items_s, items_s.data(), items_s.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
+    {
+        std::vector<int32_t> lens(items.size());
+        for (size_t i = 0; i < items.size(); ++i) lens[i] = items[i].count;
+        order_by_length(lens, c->h_order);
+        lens.resize(items_s.size());
+        for (size_t i = 0; i < items_s.size(); ++i) lens[i] = items_s[i].count;
+        order_by_length(lens, c->h_order_s);
+        if (!items.empty())
+            HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order.data(), c->h_order.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        if (!items_s.empty())
+            HIPCHK(c, hipMemcpyAsync(c->d_order_s, c->h_order_s.data(), c->h_order_s.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipMemcpyAsync(c->d_win_item0, item0_h.data(), item0_h.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_edges, ef.data(), ef.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));     // host vectors go out of scope

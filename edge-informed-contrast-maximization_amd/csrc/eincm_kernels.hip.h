@@ -423,12 +423,17 @@ __global__ __launch_bounds__(NT) void k_windows(Geom g, const double* __restrict
 // Block -> (segment, reference time).  The R blocks that process one segment at the R reference times read the
 // same events; blocks b, b+8, b+16, ... are dealt to the same XCD back to back, so they are made siblings and
 // the 2nd..Rth read of a segment's events hits that XCD's L2 instead of HBM.  grid = ceil(n_items/8)*8*R.
-__device__ __forceinline__ bool block_to_work(int n_items, int R, int& item, int& r) {
+// order (or nullptr = identity): the segments by decreasing length, so that the longest workgroups start first and the short ones
+// fill the end of the launch (the hardware dispatches workgroups in blockIdx order); which workgroup does which segment has no
+// effect on any result (integer accumulation, partials indexed by segment).
+__device__ __forceinline__ bool block_to_work(int n_items, int R, const int32_t* __restrict__ order, int& item, int& r) {
     const int b = blockIdx.x;
     const int xcd = b % NXCD, slot = b / NXCD;
-    item = (slot / R) * NXCD + xcd;
+    const int rank = (slot / R) * NXCD + xcd;
     r = slot % R;
-    return item < n_items;
+    if (rank >= n_items) return false;
+    item = order ? order[rank] : rank;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -445,14 +450,15 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
         const double* __restrict__ tmm,        // (B,ntiles,4)
         const double* __restrict__ edge_ts,    // (B,R)
         const Window* __restrict__ wins,       // (n_items, R) destination windows of this evaluation (k_theta_const / k_windows)
-        unsigned long long* __restrict__ acc)  // (B,R,H,W) u64 fixed point at 2^ACC_SHIFT, zero on entry (cleared by its consumer)
+        unsigned long long* __restrict__ acc,  // (B,R,H,W) u64 fixed point at 2^ACC_SHIFT, zero on entry (cleared by its consumer)
+        const int32_t* __restrict__ order)     // (n_items) segments by decreasing length (block_to_work)
 {
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsu[];
     float* ldsf = reinterpret_cast<float*>(ldsu + g.wincap);                       // present only when lds_multi
     double2* thtile = reinterpret_cast<double2*>(ldsu + (lds_multi ? 2 : 1) * g.wincap);   // present only for THETA_TILE
     int item, r;
-    if (!block_to_work(n_items, g.R, item, r)) return;
+    if (!block_to_work(n_items, g.R, order, item, r)) return;
     const Item it = items[item];
     const double tau = edge_ts[it.win * g.R + r];
     const int tx0 = (it.tile % g.tilesX) * TS, ty0 = (it.tile / g.tilesX) * TS;
@@ -1068,7 +1074,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
         long long* __restrict__ gTheta,        // (B,H,W,2) i64 fixed point, zero on entry (cleared by its consumer)
         int direct11, double* __restrict__ g11,                     // 2-DoF theta: (n_items, R, 2) per-workgroup partials of dL/dtheta
         const WinConst* __restrict__ wc, const unsigned* __restrict__ gmax,   // scale of the i64 accumulators (grad_shift)
-        int theta_mode)
+        int theta_mode, const int32_t* __restrict__ order)
 {
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
     // (direct11 stays a run-time flag on purpose: folding it as well made this kernel 14 % SLOWER, 132 -> 151 us)
@@ -1079,7 +1085,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
     double2* thtile = reinterpret_cast<double2*>(lds + g.wincap + (direct11 ? 0 : TS * TS * 4));
     float f11x = 0.0f, f11y = 0.0f;             // direct11: this thread's share of sum_e -dt * dL/dw
     int item, r;
-    if (!block_to_work(n_items, g.R, item, r)) return;
+    if (!block_to_work(n_items, g.R, order, item, r)) return;
     const Item it = items[item];
     const double tau = edge_ts[it.win * g.R + r];
     const Window wn = wins[(size_t)item * g.R + r];
@@ -1220,7 +1226,7 @@ __global__ __launch_bounds__(NT) void k_count(Geom g, int n_items, const Item* _
                                                const double* __restrict__ edge_ts, uint32_t* __restrict__ counts)
 {
     int item, r;
-    if (!block_to_work(n_items, g.R, item, r)) return;
+    if (!block_to_work(n_items, g.R, nullptr, item, r)) return;
     const Item it = items[item];
     const double tau = edge_ts[it.win * g.R + r];
     const double* __restrict__ Th = Theta + (size_t)it.win * g.H * g.W * 2;
