@@ -436,6 +436,26 @@ __device__ __forceinline__ bool block_to_work(int n_items, int R, const int32_t*
     return true;
 }
 
+// Flat walk over a ww x wh window by the NT threads of a workgroup: thread t visits pixels t, t + NT, t + 2 NT, ... and keeps
+// (row, col) by increments.  Row-wise loops (a wave per window row) left ww/64 of the lanes busy and paid the loop overhead per
+// row; the window copies are 10 % of the event kernels' instructions.  ww < 2^12 and t < NT, so the float quotient is within one
+// of the integer one and a single correction step makes it exact.
+struct WinWalk {
+    int i, row, col, q, rem, ww;
+    __device__ __forceinline__ WinWalk(int tid, int ww_) : ww(ww_) {
+        const float inv = 1.0f / (float)ww_;
+        row = (int)((float)tid * inv); col = tid - row * ww_;
+        if (col < 0) { col += ww_; --row; } else if (col >= ww_) { col -= ww_; ++row; }
+        q = (int)((float)NT * inv); rem = NT - q * ww_;
+        if (rem < 0) { rem += ww_; --q; } else if (rem >= ww_) { rem -= ww_; ++q; }
+        i = tid;
+    }
+    __device__ __forceinline__ void next() {
+        i += NT; col += rem; row += q;
+        if (col >= ww) { col -= ww; ++row; }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // k_splat: the dominant kernel.  grid ceil(n_items/8)*8*R blocks (block_to_work), LDS 2*WIN_CAP*4 bytes.
 // A segment is walked in chunks of <= chunk events; each chunk is accumulated in u32 fixed point (exact integer
@@ -576,11 +596,9 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {
         // the usual case, the window lies inside the image: no index rule per pixel
         unsigned long long* __restrict__ dst = img + (size_t)wn.oy * g.W + wn.ox;
-        for (int row = wv; row < wn.wh; row += NWAVE) {
-            for (int col = lane; col < wn.ww; col += 64) {
-                const unsigned long long v = to_acc(row * wn.ww + col);
-                if (v != 0ull) atomicAdd(dst + row * g.W + col, v);
-            }
+        for (WinWalk w(threadIdx.x, wn.ww); w.i < nwin; w.next()) {
+            const unsigned long long v = to_acc(w.i);
+            if (v != 0ull) atomicAdd(dst + w.row * g.W + w.col, v);
         }
         return;
     }
@@ -1093,8 +1111,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {      // the usual case: window inside the image
         const float* __restrict__ src = Gi + (size_t)wn.oy * g.W + wn.ox;
-        for (int row = wv; row < wn.wh; row += NWAVE)
-            for (int col = lane; col < wn.ww; col += 64) lds[row * wn.ww + col] = src[row * g.W + col];
+        for (WinWalk w(threadIdx.x, wn.ww); w.i < wn.ww * wn.wh; w.next()) lds[w.i] = src[w.row * g.W + w.col];
     } else {
         for (int row = wv; row < wn.wh; row += NWAVE) {
             const int gy = wrap_drop(wn.oy + row, g.H);
@@ -1166,18 +1183,19 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
                 }
             }
         }
-        // dL/dwx = sum_dx Wx[dx] (sum_dy Ky[dy] G[dy][dx]),  dL/dwy = sum_dx Kx[dx] (sum_dy Wy[dy] G[dy][dx]),  W[d] = K[d] ((d - 1) - f):
-        // 30 multiply-adds per event instead of the 42 of the tap-by-tap form
-        const float wx0 = fmaf(-kx[0], fx, -kx[0]), wx1 = -kx[1] * fx, wx2 = fmaf(-kx[2], fx, kx[2]);
-        const float wy0 = fmaf(-ky[0], fy, -ky[0]), wy1 = -ky[1] * fy, wy2 = fmaf(-ky[2], fy, ky[2]);
+        // d k(d)/dw = k(d) ((d - 1) - f) on either axis (d = 0, 1, 2 the tap index), so with S = sum_dy sum_dx Ky[dy] Kx[dx] G[dy][dx]
+        //   dL/dwx = sum_dx Kx[dx] ((dx - 1) - fx) c[dx] = (Kx[2] c[2] - Kx[0] c[0]) - fx S,   c[dx] = sum_dy Ky[dy] G[dy][dx]
+        //   dL/dwy = (Ky[2] r[2] - Ky[0] r[0]) - fy S,                                         r[dy] = sum_dx Kx[dx] G[dy][dx]
+        // 25 multiply-adds per event (the weighted-tap form W[d] = K[d] ((d - 1) - f) took 36, the tap-by-tap form 42)
         const float c0 = fmaf(ky[2], gv[2][0], fmaf(ky[1], gv[1][0], ky[0] * gv[0][0]));
         const float c1 = fmaf(ky[2], gv[2][1], fmaf(ky[1], gv[1][1], ky[0] * gv[0][1]));
         const float c2 = fmaf(ky[2], gv[2][2], fmaf(ky[1], gv[1][2], ky[0] * gv[0][2]));
-        const float d0 = fmaf(wy2, gv[2][0], fmaf(wy1, gv[1][0], wy0 * gv[0][0]));
-        const float d1 = fmaf(wy2, gv[2][1], fmaf(wy1, gv[1][1], wy0 * gv[0][1]));
-        const float d2 = fmaf(wy2, gv[2][2], fmaf(wy1, gv[1][2], wy0 * gv[0][2]));
-        const float gwx = fmaf(wx2, c2, fmaf(wx1, c1, wx0 * c0));
-        const float gwy = fmaf(kx[2], d2, fmaf(kx[1], d1, kx[0] * d0));
+        const float u0 = kx[0] * c0, u1 = kx[1] * c1, u2 = kx[2] * c2;
+        const float S = (u0 + u2) + u1;
+        const float gwx = fmaf(-fx, S, u2 - u0);
+        const float r0 = fmaf(kx[2], gv[0][2], fmaf(kx[1], gv[0][1], kx[0] * gv[0][0]));
+        const float r2 = fmaf(kx[2], gv[2][2], fmaf(kx[1], gv[2][1], kx[0] * gv[2][0]));
+        const float gwy = fmaf(-fy, S, fmaf(ky[2], r2, -(ky[0] * r0)));
         if (direct11) {          // theta (1,1,2): Theta is constant, dL/dtheta = sum over all events; no per-pixel image needed.
             // fp32 over the thread's own <= 32 terms (their rounding errors are independent across 10^6 threads and average out:
             // measured 1e-9 relative on the gradient), fp64 from there on
