@@ -258,9 +258,12 @@ __device__ __forceinline__ void warp_axis(int x, double v, double dt, int& ir, f
     const double w = (double)x - v * dt;
     const double r = rint(w);
     f = (float)(w - r);                              // garbage when the event is off-sensor, but then every tap is dropped
-    const int ri = (int)r;                           // v_cvt_i32_f64 saturates (NaN -> 0; a NaN theta is caught in k_final)
-    ir = min(max(ri, -(1 << 20)), 1 << 20);          // one v_med3_i32; |w| beyond any sensor (W, H <= 32767): every tap is dropped
+    ir = (int)r;                                     // v_cvt_i32_f64 saturates (NaN -> 0; a NaN theta is caught in k_final)
 }
+// The saturated extremes are tamed only where index arithmetic follows (the out-of-window paths): one v_med3_i32; |w| beyond any
+// sensor (W, H <= 32767) drops every tap.  The in-window test `(unsigned)(ir - 1 - ox) < ww - 2` needs no clamp: |ox| < 2^16 and
+// ww < 2^12, so a wrapped difference of a saturated ir lands near +-2^31, never inside the window.
+__device__ __forceinline__ int clamp_far(int ir) { return min(max(ir, -(1 << 20)), 1 << 20); }
 
 // (x-axis value, y-axis value).  A plain struct on purpose: as an ext_vector_type the pairs lower to v_pk_mul_f32 / v_pk_fma_f32, and on
 // gfx950 packed fp32 issues at half the rate of scalar fp32 AND needs register-pair shuffles: building with the SLP vectoriser off
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
             atomicAdd(p2, fix_u32(kp.y, km.x)); atomicAdd(p2 + 1, fix_u32(kp.y, k0.x)); atomicAdd(p2 + 2, fix_u32(kp.y, kp.x));
         } else {
             const float kx[3] = {km.x, k0.x, kp.x}, ky[3] = {km.y, k0.y, kp.y};
-            const int sx = irx, sy = iry, lxs = lx, lys = ly;
+            const int sx = clamp_far(irx), sy = clamp_far(iry), lxs = sx - 1 - wn.ox, lys = sy - 1 - wn.oy;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
@@ -1095,7 +1098,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
         int theta_mode, const int32_t* __restrict__ order)
 {
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
-    // (direct11 stays a run-time flag on purpose: folding it as well made this kernel 14 % SLOWER, 132 -> 151 us)
+    if (TM != 0) direct11 = (TM == THETA_CONST) ? 1 : 0;     // the host ties the two (2-DoF theta <=> per-workgroup partials)
     // LDS: [G window: wincap floats][accum: TS*TS*2 doubles unless direct11][Theta tile: TS*TS double2 if THETA_TILE]
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red11[NWAVE];
@@ -1166,7 +1169,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
                 for (int dx = 0; dx < 3; ++dx) gv[dy][dx] = p[dy * wn.ww + dx];
             }
         } else {
-            const int sx = irx, sy = iry, lxs = lx, lys = ly;
+            const int sx = clamp_far(irx), sy = clamp_far(iry), lxs = sx - 1 - wn.ox, lys = sy - 1 - wn.oy;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
@@ -1257,7 +1260,7 @@ __global__ __launch_bounds__(NT) void k_count(Geom g, int n_items, const Item* _
         int irx, iry; float fx, fy;
         warp_axis(x, v.x, dt, irx, fx);
         warp_axis(y, v.y, dt, iry, fy);
-        const int gx = wrap_drop(irx, g.W), gy = wrap_drop(iry, g.H);
+        const int gx = wrap_drop(clamp_far(irx), g.W), gy = wrap_drop(clamp_far(iry), g.H);
         if (gx >= 0 && gy >= 0) atomicAdd(img + (size_t)gy * g.W + gx, 1u);
     }
 }
