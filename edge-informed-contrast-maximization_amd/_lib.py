@@ -78,6 +78,7 @@ SIGNATURES = [
     ('eincm_multi_ref_weights', C.c_int, [C.c_int, _D]),
     ('eincm_resample_matrix', C.c_int, [C.c_int, C.c_int, C.c_int, _D]),
     ('eincm_get_timings', C.c_int, [_P, C.POINTER(Timings)]),
+    ('eincm_set_timed_kernels', C.c_int, [_P, C.c_int, C.c_int]),
     ('eincm_get_timings_total', C.c_int, [_P, C.POINTER(Timings), C.POINTER(C.c_int64), C.c_int]),
     ('eincm_set_windows_ex', C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int16),
                                        C.POINTER(C.c_int16), _D, _D, _D, C.c_uint32]),

@@ -6,6 +6,7 @@
 //   - build the scale_and_translate weight matrices (theta_utils.py:25-35) for the current theta shape
 //   - launch the evaluation sequence on one stream and hand (value, grad, aux) back as float64
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -117,9 +118,15 @@ struct eincm_ctx {
     OutScal* h_outs = nullptr;
     WinConst* h_wc = nullptr;
 
-    // timing
-    hipEvent_t ev[EINCM_N_STAGES + 1][2];
-    bool ev_used[EINCM_N_STAGES + 1];
+    // timing.  EINCM_CF_TIMING_DOMINANT keeps a ring of event sets and reads them out later (eincm_get_timings*): asking HIP for
+    // elapsed times after every evaluation cost the caller ~15 us per evaluation, which a throughput measurement should not pay.
+    static constexpr int EV_RING = 64;
+    hipEvent_t ev[EV_RING][EINCM_N_STAGES + 1][2] = {};
+    bool ev_used[EV_RING][EINCM_N_STAGES + 1] = {};
+    int ring_size = 1;             // EV_RING in the dominant mode, 1 otherwise (read out at once)
+    int ring_lo = 0, ring_n = 0;   // finished evaluations whose events have not been read yet: slots ring_lo .. ring_lo + ring_n - 1
+    int ring_cur = 0;              // slot of the evaluation in flight
+    bool time_splat = true, time_gather = true;   // EINCM_CF_TIMING_DOMINANT: which event kernels carry start / stop events (eincm_set_timed_kernels)
     bool have_events = false;
     eincm_timings last_t{};
     eincm_timings sum_t{};         // running sums since the last reset (eincm_get_timings_total)
@@ -230,7 +237,10 @@ void free_all(eincm_ctx* c) {
     auto FH = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
     FH(c->h_theta); FH(c->h_outs); c->h_grad = nullptr; FH(c->h_wc);
     if (c->have_events) {
-        for (int i = 0; i <= EINCM_N_STAGES; ++i) { (void)hipEventDestroy(c->ev[i][0]); (void)hipEventDestroy(c->ev[i][1]); }
+        for (int k = 0; k < eincm_ctx::EV_RING; ++k)
+            for (int i = 0; i <= EINCM_N_STAGES; ++i)
+                for (int e = 0; e < 2; ++e)
+                    if (c->ev[k][i][e]) { (void)hipEventDestroy(c->ev[k][i][e]); c->ev[k][i][e] = nullptr; }
         c->have_events = false;
     }
     if (c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
@@ -239,14 +249,29 @@ void free_all(eincm_ctx* c) {
 struct StageTimer {
     eincm_ctx* c; int stage; bool on;
     StageTimer(eincm_ctx* c_, int s) : c(c_), stage(s),
-        on((c_->cflags & EINCM_CF_TIMING) != 0 ||
-           ((c_->cflags & EINCM_CF_TIMING_DOMINANT) != 0 && (s == EINCM_STAGE_SPLAT || s == EINCM_STAGE_GATHER))) {
-        if (on) { (void)hipEventRecord(c->ev[stage][0], c->stream); }
+        on((c_->cflags & EINCM_CF_TIMING) != 0) {
+        if (on) { (void)hipEventRecord(c->ev[c->ring_cur][stage][0], c->stream); }
     }
     ~StageTimer() {
-        if (on) { (void)hipEventRecord(c->ev[stage][1], c->stream); c->ev_used[stage] = true; }
+        if (on) { (void)hipEventRecord(c->ev[c->ring_cur][stage][1], c->stream); c->ev_used[c->ring_cur][stage] = true; }
     }
 };
+
+// EINCM_CF_TIMING_DOMINANT: the two event kernels are launched with their own start / stop events (hipExtLaunchKernelGGL: the
+// dispatch's completion signal carries the timestamps).  Marker events around them (hipEventRecord) cost 25 us per evaluation in
+// barrier packets and lost launch overlap; these cost nothing measurable.
+template <typename K, typename... Args>
+void launch_timed(eincm_ctx* c, int stage, K kernel, dim3 grid, dim3 block, size_t lds, Args... args) {
+    const bool attach = (c->cflags & EINCM_CF_TIMING_DOMINANT) && !(c->cflags & EINCM_CF_TIMING) &&
+                        (stage == EINCM_STAGE_SPLAT ? c->time_splat : c->time_gather);
+    if (attach) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, c->stream, c->ev[c->ring_cur][stage][0], c->ev[c->ring_cur][stage][1], 0,
+                              args...);
+        c->ev_used[c->ring_cur][stage] = true;
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, c->stream, args...);
+    }
+}
 
 int ensure_resample(eincm_ctx* c, int h, int w, int method) {
     if (c->cur_h == h && c->cur_w == w && c->cur_method == method) return EINCM_OK;
@@ -375,11 +400,11 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
             const int lds_multi = (c->seg_s_used > c->chunk) ? 1 : 0;      // segments longer than a chunk need the f32 commit window
             const size_t lds_bytes = (size_t)(lds_multi ? 2 : 1) * g.wincap * sizeof(float)
                                    + (theta_mode == THETA_TILE ? TS * TS * sizeof(double2) : 0);
-#define SPLAT_ARGS dim3(splat_grid(c)), dim3(NT), lds_bytes, c->stream, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
+#define SPLAT_ARGS dim3(splat_grid(c)), dim3(NT), lds_bytes, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
                    c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wins_s, c->d_acc, c->d_order_s
-            if (lds_multi)                      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<0, 1>), SPLAT_ARGS);      // long segments (EINCM_SEG_SPLAT > EINCM_CHUNK)
-            else if (theta_mode == THETA_CONST) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_CONST, 0>), SPLAT_ARGS);
-            else                                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_splat<THETA_TILE, 0>), SPLAT_ARGS);
+            if (lds_multi)                      launch_timed(c, EINCM_STAGE_SPLAT, k_splat<0, 1>, SPLAT_ARGS);      // long segments (EINCM_SEG_SPLAT > EINCM_CHUNK)
+            else if (theta_mode == THETA_CONST) launch_timed(c, EINCM_STAGE_SPLAT, k_splat<THETA_CONST, 0>, SPLAT_ARGS);
+            else                                launch_timed(c, EINCM_STAGE_SPLAT, k_splat<THETA_TILE, 0>, SPLAT_ARGS);
 #undef SPLAT_ARGS
         }
     }
@@ -387,24 +412,33 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
     return EINCM_OK;
 }
 
-int collect_timings(eincm_ctx* c) {
-    if (!(c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT))) return EINCM_OK;
+// Read one finished evaluation's events (its stream work has been waited for) into last_t and the running sums.
+int read_event_slot(eincm_ctx* c, int k) {
     memset(&c->last_t, 0, sizeof c->last_t);
-    for (int s = 0; s < EINCM_N_STAGES; ++s) {
-        if (!c->ev_used[s]) continue;
+    for (int s = 0; s <= EINCM_N_STAGES; ++s) {
+        if (!c->ev_used[k][s]) continue;
         float ms = 0.f;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]));
-        c->last_t.ms[s] = ms;
-    }
-    if (c->ev_used[EINCM_N_STAGES]) {
-        float ms = 0.f;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[EINCM_N_STAGES][0], c->ev[EINCM_N_STAGES][1]));
-        c->last_t.total_ms = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[k][s][0], c->ev[k][s][1]));
+        if (s < EINCM_N_STAGES) c->last_t.ms[s] = ms; else c->last_t.total_ms = ms;
     }
     for (int s = 0; s < EINCM_N_STAGES; ++s) c->sum_t.ms[s] += c->last_t.ms[s];
     c->sum_t.total_ms += c->last_t.total_ms;
     ++c->sum_n;
     return EINCM_OK;
+}
+int drain_event_ring(eincm_ctx* c, int keep) {          // read the oldest finished evaluations until at most `keep` are left
+    while (c->ring_n > keep) {
+        const int rc = read_event_slot(c, c->ring_lo);
+        c->ring_lo = (c->ring_lo + 1) % c->ring_size; --c->ring_n;
+        if (rc) return rc;
+    }
+    return EINCM_OK;
+}
+// The evaluation in flight has finished (stream waited for): its events join the ring; read at once unless the mode defers it.
+int collect_timings(eincm_ctx* c) {
+    if (!(c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT))) return EINCM_OK;
+    ++c->ring_n;
+    return (c->ring_size == 1) ? drain_event_ring(c, 0) : EINCM_OK;
 }
 
 // First half of an evaluation: theta -> Theta -> IWE stack (k_theta, k_splat).  theta_host: (B,h,w,2) doubles.
@@ -438,9 +472,13 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         if (rc) return rc;
     }
     if (c->acc_dirty) { const int rcd = clear_accumulators(c); if (rcd) return rcd; }
-    for (int s = 0; s <= EINCM_N_STAGES; ++s) c->ev_used[s] = false;
     const bool timing = (c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)) != 0;
-    if (timing) { (void)hipEventRecord(c->ev[EINCM_N_STAGES][0], c->stream); }
+    if (timing) {
+        if (c->ring_n == c->ring_size) { const int rcr = drain_event_ring(c, c->ring_size - 1); if (rcr) return rcr; }   // ring full: read the oldest
+        c->ring_cur = (c->ring_lo + c->ring_n) % c->ring_size;
+        for (int s = 0; s <= EINCM_N_STAGES; ++s) c->ev_used[c->ring_cur][s] = false;
+        if (c->ring_size == 1) (void)hipEventRecord(c->ev[c->ring_cur][EINCM_N_STAGES][0], c->stream);    // EINCM_CF_TIMING only
+    }
 
     EvalParams ep{};
     ep.alpha = p->alpha; ep.beta = p->beta; ep.gamma = p->gamma; ep.delta = p->delta;
@@ -537,16 +575,16 @@ int eval_end_launch(eincm_ctx* c) {
             StageTimer t(c, EINCM_STAGE_GATHER);
             if (c->n_items > 0) {
 #define GATHER_ARGS dim3(event_grid(c)), dim3(NT), \
-                    g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), c->stream, \
+                    g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), \
                     g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_wins, c->d_gTheta, \
                     direct11 ? 1 : 0, c->d_g11, c->d_wc, c->d_gmax, direct11 ? THETA_CONST : THETA_TILE, c->d_order
                 if (direct11) {
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_CONST, 0>), GATHER_ARGS);
+                    launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0>, GATHER_ARGS);
                     c->g11_per_item = g.R;
                 } else if (wide) {
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_TILE, 1>), GATHER_ARGS);
+                    launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 1>, GATHER_ARGS);
                 } else {
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather<THETA_TILE, 0>), GATHER_ARGS);
+                    launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 0>, GATHER_ARGS);
                 }
 #undef GATHER_ARGS
             }
@@ -584,7 +622,7 @@ int eval_end_launch(eincm_ctx* c) {
         if (want_grad)
             HIPCHK(c, hipMemcpyAsync(c->h_grad, c->d_grad, (size_t)g.B * nth * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    if (timing) { (void)hipEventRecord(c->ev[EINCM_N_STAGES][1], c->stream); c->ev_used[EINCM_N_STAGES] = true; }
+    if (timing && c->ring_size == 1) { (void)hipEventRecord(c->ev[c->ring_cur][EINCM_N_STAGES][1], c->stream); c->ev_used[c->ring_cur][EINCM_N_STAGES] = true; }
     c->pend.launched = true;
     c->acc_dirty = false;          // every accumulator this evaluation touched has been consumed (and cleared) by the kernels above
     return EINCM_OK;
@@ -815,8 +853,14 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_coltap, (size_t)W));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_theta), B * img * 2 * sizeof(double), hipHostMallocDefault));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_wc), B * sizeof(WinConst), hipHostMallocDefault));
-    for (int i = 0; i <= EINCM_N_STAGES; ++i) { TRY(hipEventCreate(&c->ev[i][0])); TRY(hipEventCreate(&c->ev[i][1])); c->ev_used[i] = false; }
     c->have_events = true;
+    c->ring_size = (flags & EINCM_CF_TIMING_DOMINANT) && !(flags & EINCM_CF_TIMING) ? eincm_ctx::EV_RING : 1;
+    if (flags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT))
+        for (int k = 0; k < c->ring_size; ++k)
+            for (int i = 0; i <= EINCM_N_STAGES; ++i) {
+                const bool needed = (flags & EINCM_CF_TIMING) || i == EINCM_STAGE_SPLAT || i == EINCM_STAGE_GATHER || i == EINCM_N_STAGES;
+                if (needed) { TRY(hipEventCreate(&c->ev[k][i][0])); TRY(hipEventCreate(&c->ev[k][i][1])); }
+            }
     // both event kernels need > 32 KiB... (<= 64 KiB default limit is fine on gfx950, no attribute needed)
 #undef TRY
     return c;
@@ -1481,8 +1525,19 @@ int eincm_get_timings_total(eincm_ctx* c, eincm_timings* t, int64_t* n_evals, in
     if (!c || !t || !n_evals) return EINCM_ERR_ARG;
     if (!(c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)))
         return fail(c, EINCM_ERR_STATE, "context was created without EINCM_CF_TIMING / EINCM_CF_TIMING_DOMINANT");
+    if (c->pend.active) return fail(c, EINCM_ERR_STATE, "an evaluation is in flight");
+    const int rc = drain_event_ring(c, 0);
+    if (rc) return rc;
     *t = c->sum_t; *n_evals = c->sum_n;
     if (reset) { c->sum_t = eincm_timings{}; c->sum_n = 0; }
+    return EINCM_OK;
+}
+
+int eincm_set_timed_kernels(eincm_ctx* c, int splat, int gather) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!(c->cflags & EINCM_CF_TIMING_DOMINANT)) return fail(c, EINCM_ERR_STATE, "context was created without EINCM_CF_TIMING_DOMINANT");
+    if (c->pend.active) return fail(c, EINCM_ERR_STATE, "an evaluation is in flight");
+    c->time_splat = splat != 0; c->time_gather = gather != 0;
     return EINCM_OK;
 }
 
@@ -1490,6 +1545,9 @@ int eincm_get_timings(eincm_ctx* c, eincm_timings* t) {
     if (!c || !t) return EINCM_ERR_ARG;
     if (!(c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)))
         return fail(c, EINCM_ERR_STATE, "context was created without EINCM_CF_TIMING / EINCM_CF_TIMING_DOMINANT");
+    if (c->pend.active) return fail(c, EINCM_ERR_STATE, "an evaluation is in flight");
+    const int rc = drain_event_ring(c, 0);
+    if (rc) return rc;
     *t = c->last_t;
     return EINCM_OK;
 }

@@ -57,7 +57,8 @@ class Engine:
         self.H, self.W = int(sensor_size[0]), int(sensor_size[1])
         self.max_windows = int(max_windows)
         self.max_refs = int(max_refs)
-        # timing: False | True (every stage, ~10 % slower) | 'dominant' (only k_splat + whole evaluation)
+        # timing: False | True (every stage bracketed by marker events, ~20 % slower) | 'dominant' (the two event kernels
+        # launched with their own start/stop events, read out on demand: see set_timed_kernels)
         flags = 0 if not timing else (L.CF_TIMING_DOMINANT if timing == 'dominant' else L.CF_TIMING)
         self._ctx = self._lib.eincm_create(int(device), self.H, self.W, int(max_refs), int(max_windows),
                                            int(max_events_total), flags)
@@ -331,6 +332,10 @@ class Engine:
         d = {name: float(t.ms[i]) for i, name in enumerate(L.STAGE_NAMES)}
         d['total'] = float(t.total_ms)
         return d, int(n.value)
+
+    def set_timed_kernels(self, splat=True, gather=True):
+        """timing='dominant' contexts: which event kernels carry HIP timing events from the next evaluation on."""
+        self._check(self._lib.eincm_set_timed_kernels(self._ctx, 1 if splat else 0, 1 if gather else 0))
 
     def timings(self):
         t = L.Timings()

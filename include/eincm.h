@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define EINCM_ABI_VERSION 2   /* 2: eincm_iwe_device_ptr hands out the u64 fixed-point accumulator of the IWE stack */
+#define EINCM_ABI_VERSION 3   /* 2: eincm_iwe_device_ptr hands out the u64 fixed-point accumulator of the IWE stack; 3: eincm_set_timed_kernels */
 
 #define EINCM_OK               0
 #define EINCM_ERR_ARG         -1   /* bad argument (shape, null pointer, out-of-range event coordinate) */
@@ -51,7 +51,10 @@ extern "C" {
 
 /* eincm_create flags */
 #define EINCM_CF_TIMING     1u     /* bracket every kernel with HIP events (eincm_get_timings); costs ~10 % of a step */
-#define EINCM_CF_TIMING_DOMINANT 2u /* bracket only the two event kernels (k_splat, k_gather) and the whole evaluation: 6 event records */
+#define EINCM_CF_TIMING_DOMINANT 2u /* the two event kernels (k_splat, k_gather) are launched with their own start / stop events
+                                     * (hipExtLaunchKernelGGL: no marker packets on the stream) and the events are read when the
+                                     * timings are asked for, not after every evaluation; total_ms stays 0 in this mode.
+                                     * eincm_set_timed_kernels narrows it to one of the two */
 
 typedef struct eincm_ctx eincm_ctx;
 
@@ -188,6 +191,9 @@ int eincm_multi_ref_weights(int n_refs, double* w);
 int eincm_resample_matrix(int n_in, int n_out, int method, double* A);
 
 int eincm_get_timings(eincm_ctx* ctx, eincm_timings* t);
+/* EINCM_CF_TIMING_DOMINANT contexts: which of the two event kernels carry timing events from the next evaluation on (both by
+ * default).  A timed launch costs ~6 us of an evaluation; a throughput measurement times only the kernel it reports. */
+int eincm_set_timed_kernels(eincm_ctx* ctx, int splat, int gather);
 /* sums of the per-evaluation timings since the last reset, and how many evaluations they cover (a bench reads them once after
  * its timed loop instead of calling eincm_get_timings inside it) */
 int eincm_get_timings_total(eincm_ctx* ctx, eincm_timings* sum, int64_t* n_evals, int reset);

@@ -148,3 +148,44 @@ def test_float_coordinates_round_half_to_even(built_lib):
         assert v2[0] == pytest.approx(v[0], rel=1e-6) and np.abs(g - g2).max() <= 1e-6 * np.abs(g2).max()
         with pytest.raises(ValueError, match='int16'):
             e.set_window(xf + 40000.0, yf, ts, edges, edge_ts)
+
+
+def test_timing_modes_agree_and_do_not_change_results(built_lib):
+    """EINCM_CF_TIMING (marker events, read at once), EINCM_CF_TIMING_DOMINANT (events attached to the two event kernels, read on
+    demand through a ring of 64 sets) and no timing: the same numbers; the two event kernels' durations agree between the modes."""
+    wins, args = _batch(2, N=60000)
+    th = np.stack([synth.theta_near_truth(50 + b, w, (1, 1)) for b, w in enumerate(wins)])
+    p = engine.make_params(20.0, 35.0, 0.0, 0.0, 4)
+    n_tot = sum(len(a[0]) for a in args)
+    res, tim = {}, {}
+    for mode in (False, True, 'dominant'):
+        with engine.Engine((96, 128), n_tot, max_refs=3, max_windows=2, timing=mode) as e:
+            e.set_windows(args)
+            for _ in range(5):
+                e.loss_grad(th, p)
+            if mode:
+                e.timings_total(reset=True)
+            n = 100                                              # more than the ring holds: the oldest sets are read on the way
+            for _ in range(n):
+                v, g, _ = e.loss_grad(th, p)
+            res[mode] = (v, g)
+            if mode:
+                acc, cnt = e.timings_total(reset=True)
+                assert cnt == n
+                tim[mode] = {k: acc[k] / n for k in ('splat', 'gather', 'total')}
+            if mode == 'dominant':
+                assert acc['total'] == 0.0 and acc['stats'] == 0.0
+                e.set_timed_kernels(splat=True, gather=False)
+                for _ in range(3):
+                    e.loss_grad(th, p)
+                acc, cnt = e.timings_total(reset=True)
+                assert cnt == 3 and acc['splat'] > 0.0 and acc['gather'] == 0.0
+                last = e.timings()
+                assert last['splat'] > 0.0 and last['gather'] == 0.0
+            elif mode is False:
+                with pytest.raises(engine.EincmError, match='without EINCM_CF_TIMING'):
+                    e.timings_total()
+    for mode in (True, 'dominant'):
+        assert np.array_equal(res[mode][0], res[False][0]) and np.array_equal(res[mode][1], res[False][1])
+    for k in ('splat', 'gather'):                                # kernel durations of a few microseconds: same within 25 % + 2 us
+        assert abs(tim[True][k] - tim['dominant'][k]) < 0.25 * tim[True][k] + 2e-3, (k, tim)
