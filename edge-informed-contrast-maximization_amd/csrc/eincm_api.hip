@@ -126,6 +126,7 @@ struct eincm_ctx {
     int ring_size = 1;             // EV_RING in the dominant mode, 1 otherwise (read out at once)
     int ring_lo = 0, ring_n = 0;   // finished evaluations whose events have not been read yet: slots ring_lo .. ring_lo + ring_n - 1
     int ring_cur = 0;              // slot of the evaluation in flight
+    int attach_stage = -1;         // EINCM_CF_TIMING: the single-kernel stage whose launch takes its events along (StageTimer)
     bool time_splat = true, time_gather = true;   // EINCM_CF_TIMING_DOMINANT: which event kernels carry start / stop events (eincm_set_timed_kernels)
     bool have_events = false;
     eincm_timings last_t{};
@@ -246,24 +247,29 @@ void free_all(eincm_ctx* c) {
     if (c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
 }
 
+// EINCM_CF_TIMING: a stage made of ONE kernel launch (single = true) gets its start / stop events attached to that launch
+// (launch_timed: the dispatch's own timestamps, no packets on the stream); any other stage is bracketed by marker events, whose
+// barrier packets add a few microseconds to the interval they measure and to the evaluation.
 struct StageTimer {
-    eincm_ctx* c; int stage; bool on;
-    StageTimer(eincm_ctx* c_, int s) : c(c_), stage(s),
-        on((c_->cflags & EINCM_CF_TIMING) != 0) {
-        if (on) { (void)hipEventRecord(c->ev[c->ring_cur][stage][0], c->stream); }
+    eincm_ctx* c; int stage; bool on, single;
+    StageTimer(eincm_ctx* c_, int s, bool single_ = false) : c(c_), stage(s), on((c_->cflags & EINCM_CF_TIMING) != 0), single(single_) {
+        if (on && single) c->attach_stage = stage;
+        else if (on) { (void)hipEventRecord(c->ev[c->ring_cur][stage][0], c->stream); }
     }
     ~StageTimer() {
-        if (on) { (void)hipEventRecord(c->ev[c->ring_cur][stage][1], c->stream); c->ev_used[c->ring_cur][stage] = true; }
+        if (on && single) c->attach_stage = -1;
+        else if (on) { (void)hipEventRecord(c->ev[c->ring_cur][stage][1], c->stream); c->ev_used[c->ring_cur][stage] = true; }
     }
 };
 
 // EINCM_CF_TIMING_DOMINANT: the two event kernels are launched with their own start / stop events (hipExtLaunchKernelGGL: the
 // dispatch's completion signal carries the timestamps).  Marker events around them (hipEventRecord) cost 25 us per evaluation in
-// barrier packets and lost launch overlap; these cost nothing measurable.
+// barrier packets and lost launch overlap; attached events cost ~6 us per timed kernel.
 template <typename K, typename... Args>
 void launch_timed(eincm_ctx* c, int stage, K kernel, dim3 grid, dim3 block, size_t lds, Args... args) {
-    const bool attach = (c->cflags & EINCM_CF_TIMING_DOMINANT) && !(c->cflags & EINCM_CF_TIMING) &&
-                        (stage == EINCM_STAGE_SPLAT ? c->time_splat : c->time_gather);
+    const bool attach = (c->cflags & EINCM_CF_TIMING) ? c->attach_stage == stage
+                      : (c->cflags & EINCM_CF_TIMING_DOMINANT) ? (stage == EINCM_STAGE_SPLAT ? c->time_splat : stage == EINCM_STAGE_GATHER && c->time_gather)
+                      : false;
     if (attach) {
         hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, c->stream, c->ev[c->ring_cur][stage][0], c->ev[c->ring_cur][stage][1], 0,
                               args...);
@@ -376,13 +382,13 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
         HIPCHK(c, hipMemcpyAsync(c->d_theta_in, c->h_theta, (size_t)g.B * nth * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
     {
-        StageTimer t(c, EINCM_STAGE_THETA);
+        StageTimer t(c, EINCM_STAGE_THETA, const_theta && !need_theta_image);
         const int nwin_threads = (c->n_items + c->n_items_s) * g.R;
         if (const_theta) {
             c->last_theta11.assign(theta_host, theta_host + (size_t)g.B * 2);
             c->Theta_valid = false;
             if (need_theta_image) launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev);
-            hipLaunchKernelGGL(k_theta_const, dim3((std::max(g.B * g.ntiles, nwin_threads) + NT - 1) / NT), dim3(NT), 0, c->stream, g,
+            launch_timed(c, EINCM_STAGE_THETA, k_theta_const, dim3((std::max(g.B * g.ntiles, nwin_threads) + NT - 1) / NT), dim3(NT), 0, g,
                                use_arg ? 1 : 0, targ, theta_dev, c->d_tmm, c->d_edge_ts, c->n_items, c->d_items, c->d_wins,
                                c->n_items_s, c->d_items_s, c->d_wins_s);
         } else {
@@ -393,7 +399,7 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
         }
     }
     {
-        StageTimer t(c, EINCM_STAGE_SPLAT);
+        StageTimer t(c, EINCM_STAGE_SPLAT, true);
         c->acc_dirty = true;
         if (c->n_items_s > 0) {
             const int theta_mode = const_theta ? THETA_CONST : THETA_TILE;
@@ -530,15 +536,15 @@ int eval_end_launch(eincm_ctx* c) {
     const bool g2_from_imgrad = want_grad && ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG;
     const bool zero_copy_out = !identity && (size_t)g.B * nth <= ZERO_COPY_MAX;
     {
-        StageTimer t(c, EINCM_STAGE_STATS);
+        StageTimer t(c, EINCM_STAGE_STATS, g2_from_imgrad && g.ntiles >= NSPART);
         // Gradient evaluations with the grad-mag contrast take the contrast energy from k_imgrad (which computes the Scharr
         // images anyway), so the statistics are a pure streaming reduction with NSPART fat partials per image.
         // Either way the statistics pass is the consumer of the u32 accumulator: it leaves the fp32 IWE stack in d_iwe and the
         // accumulator zero again.
         if (g2_from_imgrad && g.ntiles >= NSPART) {
             g.nparts = NSPART;
-            hipLaunchKernelGGL(k_stats_stream, dim3(NSPART, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_acc, c->d_iwe, c->d_edges,
-                               c->d_parts);
+            launch_timed(c, EINCM_STAGE_STATS, k_stats_stream, dim3(NSPART, g.R, g.B), dim3(NT), 0, g, c->d_acc, c->d_iwe, c->d_edges,
+                         c->d_parts);
         } else {
             g.nparts = g.ntiles;
             const size_t ntot = (size_t)g.B * g.R * g.H * g.W;
@@ -564,15 +570,15 @@ int eval_end_launch(eincm_ctx* c) {
     for (int b = 0; b < g.B; ++b) wide = wide || (c->win_events[b] * (int64_t)g.R < 4096);
     if (want_grad) {
         {
-            StageTimer t(c, EINCM_STAGE_IMGRAD);
+            StageTimer t(c, EINCM_STAGE_IMGRAD, !div_grad);
             if (div_grad)
                 hipLaunchKernelGGL(k_divgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_parts,
                                    c->d_gdiv, c->d_dgparts);
-            hipLaunchKernelGGL(k_imgrad, dim3((g.nig + IG_NT / 64 - 1) / (IG_NT / 64), g.R, g.B), dim3(IG_NT), 0, c->stream, g, ep, c->d_iwe, c->d_edges,
+            launch_timed(c, EINCM_STAGE_IMGRAD, k_imgrad, dim3((g.nig + IG_NT / 64 - 1) / (IG_NT / 64), g.R, g.B), dim3(IG_NT), 0, g, ep, c->d_iwe, c->d_edges,
                                c->d_parts, c->d_wc, c->d_gdiv, c->d_dgparts, c->d_g2parts, c->d_G, c->d_gmax);
         }
         {
-            StageTimer t(c, EINCM_STAGE_GATHER);
+            StageTimer t(c, EINCM_STAGE_GATHER, true);
             if (c->n_items > 0) {
 #define GATHER_ARGS dim3(event_grid(c)), dim3(NT), \
                     g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), \
@@ -600,9 +606,9 @@ int eval_end_launch(eincm_ctx* c) {
         }
     }
     {
-        StageTimer t(c, EINCM_STAGE_FINAL);
+        StageTimer t(c, EINCM_STAGE_FINAL, !(want_grad && identity));
         // small results (everything but a dense gradient) are written by k_final straight into pinned host memory: no D2H copy command
-        hipLaunchKernelGGL(k_final, dim3(g.B), dim3(FT), 0, c->stream, g, ep, c->d_parts, c->d_divparts, c->d_tvparts,
+        launch_timed(c, EINCM_STAGE_FINAL, k_final, dim3(g.B), dim3(FT), 0, g, ep, c->d_parts, c->d_divparts, c->d_tvparts,
                            c->d_tmm, c->d_wc, g2_from_imgrad ? c->d_g2parts : nullptr, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap,
                            c->d_g11, c->d_win_item0, c->n_items, c->g11_per_item, c->d_gmax,
                            zero_copy_out ? c->h_outs : c->d_outs, zero_copy_out ? c->h_grad : c->d_grad, want_grad ? 1 : 0);
