@@ -10,6 +10,9 @@ Two decompositions, one JSON line each:
     own 8 windows.  Windows are independent objects, so there is NO data-path collective; for N > 1 the timed step additionally
     all-reduces the scalar batch loss over RCCL (the one collective north_star names), issued asynchronously so that it overlaps
     the next step; the same K steps are also timed without it and reported beside (`no_collective`).
+    Kernel times (`roofline`): HIP events attached to the launches on the engine's stream.  Inside the timed region only the longest
+    event kernel carries them (which one that is, is measured during the spin-up); the other one is timed in a second pass of
+    the same K steps.  Marker events around every kernel would cost 10 % of a step ("cost of measuring").
 
 --mode event-sharded (BASELINE.json config C5: 480x640, 1e7 events, R = 3, theta pyramid 1..16).  The events of ONE window are
     split over the ranks (sharding.ShardedEngine): per evaluation one all-reduce(sum) of the int64 IWE accumulator in HBM and one
