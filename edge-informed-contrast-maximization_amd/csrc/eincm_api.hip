@@ -579,18 +579,20 @@ int eval_end_launch(eincm_ctx* c) {
         }
         {
             StageTimer t(c, EINCM_STAGE_GATHER, true);
+            // 44 KB of LDS (G window + i64 accumulators + Theta tile) fit 3 workgroups per CU: 512 threads each keep 24 waves there
+            constexpr int NT_TILE = 512;
             if (c->n_items > 0) {
-#define GATHER_ARGS dim3(event_grid(c)), dim3(NT), \
+#define GATHER_ARGS(NTH) dim3(event_grid(c)), dim3(NTH), \
                     g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), \
                     g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_wins, c->d_gTheta, \
                     direct11 ? 1 : 0, c->d_g11, c->d_wc, c->d_gmax, direct11 ? THETA_CONST : THETA_TILE, c->d_order
                 if (direct11) {
-                    launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0>, GATHER_ARGS);
+                    launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT>, GATHER_ARGS(NT));
                     c->g11_per_item = g.R;
                 } else if (wide) {
-                    launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 1>, GATHER_ARGS);
+                    launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 1, NT_TILE>, GATHER_ARGS(NT_TILE));
                 } else {
-                    launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 0>, GATHER_ARGS);
+                    launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 0, NT_TILE>, GATHER_ARGS(NT_TILE));
                 }
 #undef GATHER_ARGS
             }

@@ -443,21 +443,22 @@ __device__ __forceinline__ bool block_to_work(int n_items, int R, const int32_t*
 // (row, col) by increments.  Row-wise loops (a wave per window row) left ww/64 of the lanes busy and paid the loop overhead per
 // row; the window copies are 10 % of the event kernels' instructions.  ww < 2^12 and t < NT, so the float quotient is within one
 // of the integer one and a single correction step makes it exact.
-struct WinWalk {
+template <int NTH> struct WinWalkT {
     int i, row, col, q, rem, ww;
-    __device__ __forceinline__ WinWalk(int tid, int ww_) : ww(ww_) {
+    __device__ __forceinline__ WinWalkT(int tid, int ww_) : ww(ww_) {
         const float inv = 1.0f / (float)ww_;
         row = (int)((float)tid * inv); col = tid - row * ww_;
         if (col < 0) { col += ww_; --row; } else if (col >= ww_) { col -= ww_; ++row; }
-        q = (int)((float)NT * inv); rem = NT - q * ww_;
+        q = (int)((float)NTH * inv); rem = NTH - q * ww_;
         if (rem < 0) { rem += ww_; --q; } else if (rem >= ww_) { rem -= ww_; ++q; }
         i = tid;
     }
     __device__ __forceinline__ void next() {
-        i += NT; col += rem; row += q;
+        i += NTH; col += rem; row += q;
         if (col >= ww) { col -= ww; ++row; }
     }
 };
+using WinWalk = WinWalkT<NT>;
 
 // ------------------------------------------------------------------------------------------------
 // k_splat: the dominant kernel.  grid ceil(n_items/8)*8*R blocks (block_to_work), LDS 2*WIN_CAP*4 bytes.
@@ -1086,8 +1087,8 @@ __global__ __launch_bounds__(NT) void k_divgrad(Geom g, const float* __restrict_
 // slots in index order).  Otherwise: per-pixel sums are accumulated in an LDS copy of the source tile as i64 fixed point
 // (ds_add_u64; scale grad_shift_pixel) and flushed with i64 global atomics.  Both are bit-reproducible.
 // ------------------------------------------------------------------------------------------------
-template <int TM, int WIDE>      // TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
-__global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE: 61-bit fixed point per event (tiny windows, see grad_shift_pixel)
+template <int TM, int WIDE, int NTH>      // NTH threads per workgroup: 256, or 512 where the LDS footprint allows only 3 workgroups per CU (THETA_TILE); TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
+__global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WIDE: 61-bit fixed point per event (tiny windows, see grad_shift_pixel)
         const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
         const double* __restrict__ Theta, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
         const float* __restrict__ G,           // (B,R,H,W)
@@ -1101,7 +1102,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
     if (TM != 0) direct11 = (TM == THETA_CONST) ? 1 : 0;     // the host ties the two (2-DoF theta <=> per-workgroup partials)
     // LDS: [G window: wincap floats][accum: TS*TS*2 doubles unless direct11][Theta tile: TS*TS double2 if THETA_TILE]
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ double red11[NWAVE];
+    __shared__ double red11[NTH / 64];
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(lds + g.wincap);   // i64 fixed point: ds_add_u64 (3.7 lane-ops/clk/CU; ds_add_f32: 0.33)
     double2* thtile = reinterpret_cast<double2*>(lds + g.wincap + (direct11 ? 0 : TS * TS * 4));
     float f11x = 0.0f, f11y = 0.0f;             // direct11: this thread's share of sum_e -dt * dL/dw
@@ -1114,9 +1115,9 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {      // the usual case: window inside the image
         const float* __restrict__ src = Gi + (size_t)wn.oy * g.W + wn.ox;
-        for (WinWalk w(threadIdx.x, wn.ww); w.i < wn.ww * wn.wh; w.next()) lds[w.i] = src[w.row * g.W + w.col];
+        for (WinWalkT<NTH> w(threadIdx.x, wn.ww); w.i < wn.ww * wn.wh; w.next()) lds[w.i] = src[w.row * g.W + w.col];
     } else {
-        for (int row = wv; row < wn.wh; row += NWAVE) {
+        for (int row = wv; row < wn.wh; row += NTH / 64) {
             const int gy = wrap_drop(wn.oy + row, g.H);
             for (int col = lane; col < wn.ww; col += 64) {
                 const int gx = wrap_drop(wn.ox + col, g.W);
@@ -1126,8 +1127,8 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
     }
     double gscale = 0.0;                          // 2^eg of this window's gradient accumulators
     if (!direct11) {
-        __shared__ unsigned gms[NWAVE];
-        for (int i = threadIdx.x; i < TS * TS * 2; i += NT) accum[i] = 0ull;
+        __shared__ unsigned gms[NTH / 64];
+        for (int i = threadIdx.x; i < TS * TS * 2; i += NTH) accum[i] = 0ull;
         gscale = ldexp(1.0, grad_shift_pixel(wc[it.win], gmax_of(gmax + (size_t)it.win * g.R * g.nig, g.R * g.nig, gms), g.R, WIDE != 0));
     }
     const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
@@ -1138,7 +1139,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
         vconst = make_double2(mm[0], mm[2]);
     } else {
         const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
-        for (int p = threadIdx.x; p < TS * TS; p += NT) {
+        for (int p = threadIdx.x; p < TS * TS; p += NTH) {
             const int y = y0 + p / TS, x = x0 + p % TS;
             thtile[p] = (y < g.H && x < g.W) ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : make_double2(0.0, 0.0);
         }
@@ -1214,13 +1215,13 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
     // a plain strided loop: with 8 waves per SIMD the loads are hidden by occupancy; the renamed-register pipeline of
     // k_splat measured 2.5 % slower here (133 vs 130 us)
 #pragma unroll 2
-    for (int e = tid; e < n; e += NT) {
+    for (int e = tid; e < n; e += NTH) {
         EvReg ev; ev.xy = exy[e]; ev.t = et[e];
         gather_ev(ev);
     }
     if (direct11) {
-        double sum11x = block_sum((double)f11x, red11);
-        double sum11y = block_sum((double)f11y, red11);
+        double sum11x = block_sum<NTH / 64>((double)f11x, red11);
+        double sum11y = block_sum<NTH / 64>((double)f11y, red11);
         if (threadIdx.x == 0) {          // own slot, plain store, written unconditionally: nothing to clear, nothing to order
             double* dst = g11 + ((size_t)item * g.R + r) * 2;
             dst[0] = sum11x; dst[1] = sum11y;
@@ -1230,7 +1231,7 @@ __global__ __launch_bounds__(NT) void k_gather(Geom g, int n_items,      // WIDE
     __syncthreads();
     unsigned long long* __restrict__ gT = reinterpret_cast<unsigned long long*>(gTheta) + (size_t)it.win * g.H * g.W * 2;
     const int tw = min(TS, g.W - x0), th = min(TS, g.H - y0);
-    for (int i = threadIdx.x; i < TS * TS * 2; i += NT) {
+    for (int i = threadIdx.x; i < TS * TS * 2; i += NTH) {
         const int c = i & 1, px = (i >> 1) % TS, py = (i >> 1) / TS;
         const unsigned long long v = accum[i];
         if (px < tw && py < th && v != 0ull) atomicAdd(gT + ((size_t)(y0 + py) * g.W + (x0 + px)) * 2 + c, v);
