@@ -406,11 +406,11 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
             const int lds_multi = (c->seg_s_used > c->chunk) ? 1 : 0;      // segments longer than a chunk need the f32 commit window
             const size_t lds_bytes = (size_t)(lds_multi ? 2 : 1) * g.wincap * sizeof(float)
                                    + (theta_mode == THETA_TILE ? TS * TS * sizeof(double2) : 0);
-#define SPLAT_ARGS dim3(splat_grid(c)), dim3(NT), lds_bytes, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
+#define SPLAT_ARGS(NTH) dim3(splat_grid(c)), dim3(NTH), lds_bytes, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
                    c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wins_s, c->d_acc, c->d_order_s
-            if (lds_multi)                      launch_timed(c, EINCM_STAGE_SPLAT, k_splat<0, 1>, SPLAT_ARGS);      // long segments (EINCM_SEG_SPLAT > EINCM_CHUNK)
-            else if (theta_mode == THETA_CONST) launch_timed(c, EINCM_STAGE_SPLAT, k_splat<THETA_CONST, 0>, SPLAT_ARGS);
-            else                                launch_timed(c, EINCM_STAGE_SPLAT, k_splat<THETA_TILE, 0>, SPLAT_ARGS);
+            if (lds_multi)                      launch_timed(c, EINCM_STAGE_SPLAT, k_splat<0, 1, NT>, SPLAT_ARGS(NT));      // long segments (EINCM_SEG_SPLAT > EINCM_CHUNK)
+            else if (theta_mode == THETA_CONST) launch_timed(c, EINCM_STAGE_SPLAT, k_splat<THETA_CONST, 0, NT>, SPLAT_ARGS(NT));
+            else                                launch_timed(c, EINCM_STAGE_SPLAT, k_splat<THETA_TILE, 0, 512>, SPLAT_ARGS(512));
 #undef SPLAT_ARGS
         }
     }

@@ -465,8 +465,8 @@ using WinWalk = WinWalkT<NT>;
 // A segment is walked in chunks of <= chunk events; each chunk is accumulated in u32 fixed point (exact integer
 // ds_add_u32) and committed into the segment's f32 window; the window is flushed to HBM once per segment.
 // ------------------------------------------------------------------------------------------------
-template <int TM, int MULTI>   // TM: the theta mode as a compile-time constant (0 = run-time argument); MULTI = 0: no segment is longer than a chunk
-__global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, int theta_mode, int lds_multi,
+template <int TM, int MULTI, int NTH>   // TM: the theta mode as a compile-time constant (0 = run-time argument); MULTI = 0: no segment is longer than a chunk
+__global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, int theta_mode, int lds_multi,
         const Item* __restrict__ items,
         const uint32_t* __restrict__ ev_xy,    // x | y << 16, binned by (window, tile)
         const double* __restrict__ ev_t,
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
         vconst = make_double2(mm[0], mm[2]);
     } else {
         const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
-        for (int p = threadIdx.x; p < TS * TS; p += NT) {
+        for (int p = threadIdx.x; p < TS * TS; p += NTH) {
             const int y = ty0 + p / TS, x = tx0 + p % TS;
             thtile[p] = (y < g.H && x < g.W) ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : make_double2(0.0, 0.0);
         }
@@ -503,8 +503,8 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     {   // clear the window(s), 16 B per lane
         uint4* z = reinterpret_cast<uint4*>(ldsu);
         const int nq = (nwin + 3) >> 2;
-        for (int i = threadIdx.x; i < nq; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (multi) { uint4* zf = reinterpret_cast<uint4*>(ldsf); for (int i = threadIdx.x; i < nq; i += NT) zf[i] = make_uint4(0u, 0u, 0u, 0u); }
+        for (int i = threadIdx.x; i < nq; i += NTH) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (multi) { uint4* zf = reinterpret_cast<uint4*>(ldsf); for (int i = threadIdx.x; i < nq; i += NTH) zf[i] = make_uint4(0u, 0u, 0u, 0u); }
     }
     __syncthreads();
 
@@ -512,8 +512,8 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     const uint32_t* __restrict__ exy = ev_xy + it.begin;
     const double* __restrict__ et = ev_t + it.begin;
     const int n = it.count;
-    const int iters = (n + NT - 1) / NT;            // uniform over the workgroup
-    const int ipc = chunk / NT;                     // iterations per chunk (chunk is a multiple of NT)
+    const int iters = (n + NTH - 1) / NTH;            // uniform over the workgroup
+    const int ipc = chunk / NTH;                     // iterations per chunk (chunk is a multiple of NTH)
     int fshift = fix_shift(min(chunk, n));
     float FIX_SCALE = ldexpf(1.0f, fshift), FIX_INV = ldexpf(1.0f, -fshift);
 
@@ -563,24 +563,24 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     };
     // one pipeline step: cur is splatted, nxt gets its (xy, t); j = iteration index of cur
     auto step = [&](EvReg& cur, EvReg& mid, EvReg& nxt, int j) {
-        const int e = j * NT + tid;
-        load_ev(nxt, e + 2 * NT);
+        const int e = j * NTH + tid;
+        load_ev(nxt, e + 2 * NTH);
         if (e < n) splat_ev(cur);
         if (multi && ((j + 1) % ipc == 0 || j + 1 == iters)) {     // chunk boundary (uniform): commit u32 -> f32 window
             __syncthreads();
-            for (int i = tid; i < nwin; i += NT) {
+            for (int i = tid; i < nwin; i += NTH) {
                 const uint32_t u = ldsu[i];
                 if (u != 0u) { ldsf[i] += (float)u * FIX_INV; ldsu[i] = 0u; }
             }
             __syncthreads();
-            fshift = fix_shift(min(chunk, n - (j + 1) * NT));
+            fshift = fix_shift(min(chunk, n - (j + 1) * NTH));
             FIX_SCALE = ldexpf(1.0f, fshift); FIX_INV = ldexpf(1.0f, -fshift);
             scy = INV_2PI * FIX_SCALE;
         }
     };
     EvReg A, B, C;
     load_ev(A, tid);
-    load_ev(B, tid + NT);
+    load_ev(B, tid + NTH);
     C.xy = 0u; C.t = 0.0;
     for (int j = 0; j < iters; j += 3) {
         step(A, B, C, j);
@@ -600,13 +600,13 @@ __global__ __launch_bounds__(NT) void k_splat(Geom g, int n_items, int chunk, in
     if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {
         // the usual case, the window lies inside the image: no index rule per pixel
         unsigned long long* __restrict__ dst = img + (size_t)wn.oy * g.W + wn.ox;
-        for (WinWalk w(threadIdx.x, wn.ww); w.i < nwin; w.next()) {
+        for (WinWalkT<NTH> w(threadIdx.x, wn.ww); w.i < nwin; w.next()) {
             const unsigned long long v = to_acc(w.i);
             if (v != 0ull) atomicAdd(dst + w.row * g.W + w.col, v);
         }
         return;
     }
-    for (int row = wv; row < wn.wh; row += NWAVE) {
+    for (int row = wv; row < wn.wh; row += NTH / 64) {
         const int gy = wrap_drop(wn.oy + row, g.H);
         if (gy < 0) continue;
         for (int col = lane; col < wn.ww; col += 64) {
