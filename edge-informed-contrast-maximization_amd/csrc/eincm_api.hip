@@ -601,8 +601,8 @@ int eval_end_launch(eincm_ctx* c) {
         // 2-DoF theta: k_gather left per-workgroup partials of the event gradient for k_final; only the TV image needs projecting.
         const int nsrc = (direct11 ? 0 : 1) + (ep.use_tv_grad ? 1 : 0);
         if (!identity && nsrc > 0) {
-            StageTimer t(c, EINCM_STAGE_PROJECT);
-            hipLaunchKernelGGL(k_project, dim3(g.ntiles, g.B, nsrc), dim3(NT), 0, c->stream, g, h, w,
+            StageTimer t(c, EINCM_STAGE_PROJECT, true);
+            launch_timed(c, EINCM_STAGE_PROJECT, k_project, dim3(g.ntiles, g.B, nsrc), dim3(NT), 0, g, h, w,
                                (int)c->coarse_cap, direct11 ? 1 : 0, wide ? 1 : 0, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_gTheta, c->d_tvg,
                                c->d_wc, c->d_gmax, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap);
         }

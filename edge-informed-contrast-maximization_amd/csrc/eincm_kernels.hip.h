@@ -295,6 +295,58 @@ constexpr int THETA_TILE = 2;    // otherwise: the tile's 32x32 double2 velociti
 // round-to-nearest fixed-point conversion of a positive value: fma + truncating convert (2 instructions)
 __device__ __forceinline__ uint32_t fix_u32(float a, float b) { return (uint32_t)fmaf(a, b, 0.5f); }
 
+// The rows of A_H and the columns of A_W that one 32x32 tile needs, staged in LDS by the whole workgroup (k_theta, k_project).
+// Per-pixel reads of the tap ranges and weights from global memory were chains of dependent loads: 12 us of k_theta and 18-30 us
+// of k_project were that latency.  A tile touches the coarse rows [ilo, ilo + ni) and columns [jlo, jlo + nj); staged when both
+// fit RS_MAXC (theta grids up to ~100 cells per axis at the usual sensors; anything else keeps the direct path).
+constexpr int RS_MAXC = 24;
+struct ResampleTile {
+    int ilo, ni, jlo, nj;
+    bool staged;
+};
+struct ResampleLds {
+    int2 rt[TS], ct[TS];
+    double ah[TS * RS_MAXC], aw[TS * RS_MAXC];
+    int rng[4];
+};
+// Two steps, each called by every thread of the workgroup (>= 64 threads) and each ending in a __syncthreads: the tap ranges of the
+// tile's rows and columns (-> which coarse cells it touches), then the weights.  A caller issues whatever else depends only on the
+// ranges (k_theta: its theta cells) between the two, so that it shares the second round trip.
+__device__ __forceinline__ ResampleTile stage_resample_ranges(ResampleLds& L, int h, int w, int x0, int y0, int x1, int y1,
+                                                              const int2* __restrict__ rowtap, const int2* __restrict__ coltap) {
+    const int t = threadIdx.x;
+    if (t < TS) L.rt[t] = (y0 + t < y1) ? rowtap[y0 + t] : make_int2(h, 0);
+    else if (t < 2 * TS) L.ct[t - TS] = (x0 + t - TS < x1) ? coltap[x0 + t - TS] : make_int2(w, 0);
+    __syncthreads();
+    if (t < 64) {                                   // lanes 0..31: rows, 32..63: columns; min / max inside each half
+        const int2 v = (t < TS) ? L.rt[t] : L.ct[t - TS];
+        int lo = v.x, hi = v.y;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+        if (t == 0) { L.rng[0] = lo; L.rng[1] = hi; }
+        if (t == TS) { L.rng[2] = lo; L.rng[3] = hi; }
+    }
+    __syncthreads();
+    ResampleTile r;
+    r.ilo = L.rng[0]; r.ni = max(L.rng[1] - L.rng[0], 0); r.jlo = L.rng[2]; r.nj = max(L.rng[3] - L.rng[2], 0);
+    r.staged = r.ni <= RS_MAXC && r.nj <= RS_MAXC;
+    return r;
+}
+__device__ __forceinline__ void stage_resample_weights(ResampleLds& L, const ResampleTile& r, int h, int w, int x0, int y0, int x1, int y1,
+                                                       const double* __restrict__ AH, const double* __restrict__ AW) {
+    if (!r.staged) return;                          // uniform
+    const int t = threadIdx.x;
+    for (int k = t; k < TS * r.ni; k += blockDim.x) {
+        const int ly = k / r.ni, i = k - ly * r.ni;
+        L.ah[k] = (y0 + ly < y1) ? AH[(size_t)(y0 + ly) * h + r.ilo + i] : 0.0;
+    }
+    for (int k = t; k < TS * r.nj; k += blockDim.x) {
+        const int lx = k / r.nj, j = k - lx * r.nj;
+        L.aw[k] = (x0 + lx < x1) ? AW[(size_t)(x0 + lx) * w + r.jlo + j] : 0.0;
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_theta: Theta = A_H theta A_W^T per channel, and per-tile velocity bounds.
 // grid (ntiles, B).  identity: theta already is (H,W,2).  Not launched for 2-DoF theta unless somebody needs the Theta image
@@ -311,17 +363,47 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
 {
     __shared__ double red[4][NWAVE];
     __shared__ double nanred[NWAVE];
+    __shared__ ResampleLds RL;
+    __shared__ double2 sth[RS_MAXC * RS_MAXC];      // the coarse cells under this tile
     const int tile = blockIdx.x, b = blockIdx.y;
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const double* th = theta + (size_t)b * h * w * 2;
     double* Th = Theta + (size_t)b * g.H * g.W * 2;
     double mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
     bool nan = false;
+    ResampleTile rs{};
+    if (!identity) {
+        const int tx0 = tx * TS, ty0 = ty * TS, tx1 = min(tx * TS + TS, g.W), ty1 = min(ty * TS + TS, g.H);
+        rs = stage_resample_ranges(RL, h, w, tx0, ty0, tx1, ty1, rowtap, coltap);
+        if (rs.staged) {                            // theta is read once per cell and workgroup (it may live in pinned host memory)
+            for (int k = threadIdx.x; k < rs.ni * rs.nj; k += NT) {
+                const int i = rs.ilo + k / rs.nj, j = rs.jlo + k % rs.nj;
+                const int o = ((b * h + i) * w + j) * 2;
+                sth[k] = use_arg ? make_double2(targ.v[o], targ.v[o + 1])
+                                 : *reinterpret_cast<const double2*>(th + ((size_t)i * w + j) * 2);
+            }
+        }
+        stage_resample_weights(RL, rs, h, w, tx0, ty0, tx1, ty1, AH, AW);      // its barrier covers sth as well
+    }
     for (int p = threadIdx.x; p < TS * TS; p += NT) {
-        const int y = ty * TS + p / TS, x = tx * TS + p % TS;
+        const int ly = p / TS, lx = p % TS;
+        const int y = ty * TS + ly, x = tx * TS + lx;
         if (y >= g.H || x >= g.W) continue;
         double vx, vy;
-        if (use_arg) {
+        if (rs.staged) {                            // the same operations in the same order as the direct forms below
+            const int2 rt = RL.rt[ly], ct = RL.ct[lx];
+            vx = 0.0; vy = 0.0;
+            for (int i = rt.x; i < rt.y; ++i) {
+                const double a = RL.ah[ly * rs.ni + (i - rs.ilo)];
+                double sx = 0.0, sy = 0.0;
+                for (int j = ct.x; j < ct.y; ++j) {
+                    const double bw = RL.aw[lx * rs.nj + (j - rs.jlo)];
+                    const double2 v = sth[(i - rs.ilo) * rs.nj + (j - rs.jlo)];
+                    sx += bw * v.x; sy += bw * v.y;
+                }
+                vx += a * sx; vy += a * sy;
+            }
+        } else if (use_arg) {
             const int2 rt = rowtap[y], ct = coltap[x];
             vx = 0.0; vy = 0.0;
             for (int i = rt.x; i < rt.y; ++i) {
@@ -1460,53 +1542,121 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
         long long* __restrict__ gth_main, long long* __restrict__ gth_tv)   // (B,cap) each, zero on entry (k_final clears)
 {
     __shared__ double scratch[NWAVE];
-    __shared__ int rng[4];
-    __shared__ unsigned long long cells[PROJ_CELLS * 2];
+    __shared__ ResampleLds RL;
+    static_assert(PROJ_CELLS * 2 >= TS * TS * 2, "cells doubles as the tile buffer of the staged path");
+    __shared__ __attribute__((aligned(16))) unsigned long long cells[PROJ_CELLS * 2 + TS * RS_MAXC * 2];   // staged path: sv (TS*TS double2) + st (TS*nj double2)
     const int tile = blockIdx.x, b = blockIdx.y, src = blockIdx.z + src0;
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
     const int x1 = min(x0 + TS, g.W), y1 = min(y0 + TS, g.H);
-    if (threadIdx.x == 0) {
-        int ilo = h, ihi = 0, jlo = w, jhi = 0;
-        for (int y = y0; y < y1; ++y) { ilo = min(ilo, rowtap[y].x); ihi = max(ihi, rowtap[y].y); }
-        for (int x = x0; x < x1; ++x) { jlo = min(jlo, coltap[x].x); jhi = max(jhi, coltap[x].y); }
-        rng[0] = ilo; rng[1] = ihi; rng[2] = jlo; rng[3] = jhi;
+    // this tile's pixels, requested before the weights are staged (their latency hides behind the staging)
+    long long pix[TS * TS / NT][2];
+    double pixd[TS * TS / NT][2];
+#pragma unroll
+    for (int k = 0; k < TS * TS / NT; ++k) {
+        const int p = threadIdx.x + k * NT;
+        const int y = y0 + p / TS, x = x0 + p % TS;
+        const bool in = (y < g.H && x < g.W);
+        const size_t o = ((size_t)b * g.H * g.W + (size_t)min(y, g.H - 1) * g.W + min(x, g.W - 1)) * 2;
+        pix[k][0] = 0; pix[k][1] = 0; pixd[k][0] = 0.0; pixd[k][1] = 0.0;
+        if (src == 0) {
+            const longlong2 v = *reinterpret_cast<const longlong2*>(gTheta + o);
+            if (in) { pix[k][0] = v.x; pix[k][1] = v.y; }
+        } else {
+            const double2 v = *reinterpret_cast<const double2*>(tvg + o);
+            if (in) { pixd[k][0] = v.x; pixd[k][1] = v.y; }
+        }
     }
-    __syncthreads();
-    const int ilo = rng[0], ihi = rng[1], jlo = rng[2], jhi = rng[3];
-    const int ni = max(ihi - ilo, 0), nj = max(jhi - jlo, 0), ncell = ni * nj;
+    __shared__ unsigned gms[NWAVE];
+    const double gm = gmax_of(gmax + (size_t)b * g.R * g.nig, g.R * g.nig, gms);       // independent of the rest: its loads go first
+    const ResampleTile rs = stage_resample_ranges(RL, h, w, x0, y0, x1, y1, rowtap, coltap);
+    stage_resample_weights(RL, rs, h, w, x0, y0, x1, y1, AH, AW);
+    const int ilo = rs.ilo, jlo = rs.jlo, ni = rs.ni, nj = rs.nj, ncell = ni * nj;
     unsigned long long* __restrict__ out = reinterpret_cast<unsigned long long*>(src == 0 ? gth_main : gth_tv) + (size_t)b * cap;
     // src 0: integers at the fine per-pixel scale -> the coarser cell scale (one rounding per pixel and weight).
     // src 1: fp64 TV gradient image -> fixed point at tv_shift.
-    __shared__ unsigned gms[NWAVE];
-    const double gm = gmax_of(gmax + (size_t)b * g.R * g.nig, g.R * g.nig, gms);
     const double scale = (src == 0) ? ldexp(1.0, grad_shift(wc[b], gm, g.R) - grad_shift_pixel(wc[b], gm, g.R, wide != 0))
                                     : ldexp(1.0, tv_shift(g.H, g.W));
+    if (rs.staged) {
+        // Separable and ordered: A) every (pixel row, coarse column) sums its row of the tile against A_W, B) every (coarse row,
+        // coarse column) sums the 32 partials against A_H - fp64, fixed order, no atomics inside the workgroup, one rounding per
+        // tile and cell.  (Every pixel adding its taps x taps products into LDS cell accumulators put 1024 pixels on <= 9
+        // addresses: ds_add_u64 at the same-address rate, 28 us per launch.)
+        double2* sv = reinterpret_cast<double2*>(cells);                 // (TS*TS) the tile's values at the cell scale, 16 KB
+        double2* st = sv + TS * TS;                                      // (TS, nj) column-reduced rows
+#pragma unroll
+        for (int k = 0; k < TS * TS / NT; ++k) {
+            const int p = threadIdx.x + k * NT;
+            const int y = y0 + p / TS, x = x0 + p % TS;
+            double vx = 0.0, vy = 0.0;
+            if (y < g.H && x < g.W) {
+                if (src == 0) {
+                    if (pix[k][0] != 0 || pix[k][1] != 0) {
+                        const size_t o = ((size_t)b * g.H * g.W + (size_t)y * g.W + x) * 2;
+                        *reinterpret_cast<longlong2*>(gTheta + o) = make_longlong2(0, 0);   // consumed: zero again for the next evaluation
+                        vx = (double)pix[k][0] * scale; vy = (double)pix[k][1] * scale;     // exact conversion for |.| < 2^53 (always, unless `wide`)
+                    }
+                } else {
+                    vx = pixd[k][0] * scale; vy = pixd[k][1] * scale;
+                }
+            }
+            sv[p] = make_double2(vx, vy);
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < TS * nj; k += NT) {
+            const int ly = k / nj, jj = k - ly * nj;
+            double ax = 0.0, ay = 0.0;
+            for (int lx = 0; lx < TS; ++lx) {                            // weights outside a pixel's tap range are stored as zeros
+                const double wgt = RL.aw[lx * nj + jj];
+                const double2 v = sv[ly * TS + lx];
+                ax += wgt * v.x; ay += wgt * v.y;
+            }
+            st[k] = make_double2(ax, ay);
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < ncell; k += NT) {
+            const int ii = k / nj, jj = k - ii * nj;
+            double ax = 0.0, ay = 0.0;
+            for (int ly = 0; ly < TS; ++ly) {
+                const double wgt = RL.ah[ly * ni + ii];
+                const double2 v = st[ly * nj + jj];
+                ax += wgt * v.x; ay += wgt * v.y;
+            }
+            unsigned long long* o = out + ((size_t)(ilo + ii) * w + (jlo + jj)) * 2;
+            if (ax != 0.0) atomicAdd(o, (unsigned long long)fix64_wide(ax));
+            if (ay != 0.0) atomicAdd(o + 1, (unsigned long long)fix64_wide(ay));
+        }
+        return;
+    }
+    // theta grids too fine for the staged weights (more than RS_MAXC coarse rows or columns under one tile): per-pixel products
     const bool use_lds = (ncell > 1 && ncell <= PROJ_CELLS);
     if (use_lds) {
         for (int i = threadIdx.x; i < ncell * 2; i += NT) cells[i] = 0ull;
         __syncthreads();
     }
     double sx1 = 0.0, sy1 = 0.0;                    // single-cell path
-    for (int p = threadIdx.x; p < TS * TS; p += NT) {
-        const int y = y0 + p / TS, x = x0 + p % TS;
+#pragma unroll
+    for (int k = 0; k < TS * TS / NT; ++k) {
+        const int p = threadIdx.x + k * NT;
+        const int ly = p / TS, lx = p % TS;
+        const int y = y0 + ly, x = x0 + lx;
         if (y >= g.H || x >= g.W) continue;
         const size_t o = ((size_t)b * g.H * g.W + (size_t)y * g.W + x) * 2;
         double vx, vy;
         if (src == 0) {
-            const long long ix = gTheta[o], iy = gTheta[o + 1];
+            const long long ix = pix[k][0], iy = pix[k][1];
             if (ix == 0 && iy == 0) continue;
-            gTheta[o] = 0; gTheta[o + 1] = 0;       // consumed: zero again for the next evaluation
+            *reinterpret_cast<longlong2*>(gTheta + o) = make_longlong2(0, 0);       // consumed: zero again for the next evaluation
             vx = (double)ix * scale; vy = (double)iy * scale;       // (double)ix exact for |.| < 2^53 (always, unless `wide`)
         } else {
-            vx = tvg[o] * scale; vy = tvg[o + 1] * scale;
+            vx = pixd[k][0] * scale; vy = pixd[k][1] * scale;
             if (vx == 0.0 && vy == 0.0) continue;
         }
-        const int2 rt = rowtap[y], ct = coltap[x];
+        const int2 rt = RL.rt[ly], ct = RL.ct[lx];
         for (int i = rt.x; i < rt.y; ++i) {
-            const double a = AH[(size_t)y * h + i];
+            const double a = rs.staged ? RL.ah[ly * ni + (i - ilo)] : AH[(size_t)y * h + i];
             for (int j = ct.x; j < ct.y; ++j) {
-                const double wt = a * AW[(size_t)x * w + j];
+                const double wt = a * (rs.staged ? RL.aw[lx * nj + (j - jlo)] : AW[(size_t)x * w + j]);
                 if (ncell == 1) { sx1 += wt * vx; sy1 += wt * vy; }
                 else if (use_lds) {
                     unsigned long long* c = cells + ((i - ilo) * nj + (j - jlo)) * 2;
