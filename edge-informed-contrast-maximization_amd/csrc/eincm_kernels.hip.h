@@ -1160,6 +1160,57 @@ __global__ __launch_bounds__(NT) void k_divgrad(Geom g, const float* __restrict_
     }
 }
 
+// dL/dw of one event at one reference time: the event is warped like in the forward pass, its 3x3 neighbourhood of G = dL/dIWE is
+// read from the LDS window `lds` (bounding box wn; taps outside it straight from the image Gi with the JAX wrap/drop rule).
+__device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, const float* lds, const float* __restrict__ Gi,
+                                           int x, int y, double2 v, double dt, float& gwx, float& gwy) {
+    int irx, iry; float fx, fy;
+    warp_axis(x, v.x, dt, irx, fx);
+    warp_axis(y, v.y, dt, iry, fy);
+    f2v km, k0, kp;
+    taps3x2(fx, fy, INV_2PI, km, k0, kp);
+    const float kx[3] = {km.x, k0.x, kp.x}, ky[3] = {km.y, k0.y, kp.y};
+    float gv[3][3];
+    const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;
+    if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
+        const float* p = lds + __mul24(ly, wn.ww) + lx;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) gv[dy][dx] = p[dy * wn.ww + dx];
+        }
+    } else {
+        const int sx = clamp_far(irx), sy = clamp_far(iry), lxs = sx - 1 - wn.ox, lys = sy - 1 - wn.oy;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int cx = lxs + dx, cy = lys + dy;
+                float val = 0.0f;
+                if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
+                    val = lds[cy * wn.ww + cx];
+                } else {
+                    const int gx = wrap_drop(sx - 1 + dx, g.W), gy = wrap_drop(sy - 1 + dy, g.H);
+                    if (gx >= 0 && gy >= 0) val = Gi[(size_t)gy * g.W + gx];
+                }
+                gv[dy][dx] = val;
+            }
+        }
+    }
+    // d k(d)/dw = k(d) ((d - 1) - f) on either axis (d = 0, 1, 2 the tap index), so with S = sum_dy sum_dx Ky[dy] Kx[dx] G[dy][dx]
+    //   dL/dwx = sum_dx Kx[dx] ((dx - 1) - fx) c[dx] = (Kx[2] c[2] - Kx[0] c[0]) - fx S,   c[dx] = sum_dy Ky[dy] G[dy][dx]
+    //   dL/dwy = (Ky[2] r[2] - Ky[0] r[0]) - fy S,                                         r[dy] = sum_dx Kx[dx] G[dy][dx]
+    // 25 multiply-adds per event (the weighted-tap form W[d] = K[d] ((d - 1) - f) took 36, the tap-by-tap form 42)
+    const float c0 = fmaf(ky[2], gv[2][0], fmaf(ky[1], gv[1][0], ky[0] * gv[0][0]));
+    const float c1 = fmaf(ky[2], gv[2][1], fmaf(ky[1], gv[1][1], ky[0] * gv[0][1]));
+    const float c2 = fmaf(ky[2], gv[2][2], fmaf(ky[1], gv[1][2], ky[0] * gv[0][2]));
+    const float u0 = kx[0] * c0, u1 = kx[1] * c1, u2 = kx[2] * c2;
+    const float S = (u0 + u2) + u1;
+    gwx = fmaf(-fx, S, u2 - u0);
+    const float r0 = fmaf(kx[2], gv[0][2], fmaf(kx[1], gv[0][1], kx[0] * gv[0][0]));
+    const float r2 = fmaf(kx[2], gv[2][2], fmaf(kx[1], gv[2][1], kx[0] * gv[2][0]));
+    gwy = fmaf(-fy, S, fmaf(ky[2], r2, -(ky[0] * r0)));}
+
 // ------------------------------------------------------------------------------------------------
 // k_gather: reverse of the splat.  grid as k_splat (block_to_work).  For every event of the segment and this reference time:
 //   dL/dwx = sum_taps G[p] * k * qx,  dL/dwy likewise (q = p - w; dropped taps contribute 0, wrapped taps read
@@ -1236,52 +1287,8 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         const double dt = ev.t - tau;
         const int x = ev.xy & 0xffff, y = ev.xy >> 16;
         const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)];
-        int irx, iry; float fx, fy;
-        warp_axis(x, v.x, dt, irx, fx);
-        warp_axis(y, v.y, dt, iry, fy);
-        f2v km, k0, kp;
-        taps3x2(fx, fy, INV_2PI, km, k0, kp);
-        const float kx[3] = {km.x, k0.x, kp.x}, ky[3] = {km.y, k0.y, kp.y};
-        float gv[3][3];
-        const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;
-        if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
-            const float* p = lds + __mul24(ly, wn.ww) + lx;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) gv[dy][dx] = p[dy * wn.ww + dx];
-            }
-        } else {
-            const int sx = clamp_far(irx), sy = clamp_far(iry), lxs = sx - 1 - wn.ox, lys = sy - 1 - wn.oy;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int cx = lxs + dx, cy = lys + dy;
-                    float val = 0.0f;
-                    if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
-                        val = lds[cy * wn.ww + cx];
-                    } else {
-                        const int gx = wrap_drop(sx - 1 + dx, g.W), gy = wrap_drop(sy - 1 + dy, g.H);
-                        if (gx >= 0 && gy >= 0) val = Gi[(size_t)gy * g.W + gx];
-                    }
-                    gv[dy][dx] = val;
-                }
-            }
-        }
-        // d k(d)/dw = k(d) ((d - 1) - f) on either axis (d = 0, 1, 2 the tap index), so with S = sum_dy sum_dx Ky[dy] Kx[dx] G[dy][dx]
-        //   dL/dwx = sum_dx Kx[dx] ((dx - 1) - fx) c[dx] = (Kx[2] c[2] - Kx[0] c[0]) - fx S,   c[dx] = sum_dy Ky[dy] G[dy][dx]
-        //   dL/dwy = (Ky[2] r[2] - Ky[0] r[0]) - fy S,                                         r[dy] = sum_dx Kx[dx] G[dy][dx]
-        // 25 multiply-adds per event (the weighted-tap form W[d] = K[d] ((d - 1) - f) took 36, the tap-by-tap form 42)
-        const float c0 = fmaf(ky[2], gv[2][0], fmaf(ky[1], gv[1][0], ky[0] * gv[0][0]));
-        const float c1 = fmaf(ky[2], gv[2][1], fmaf(ky[1], gv[1][1], ky[0] * gv[0][1]));
-        const float c2 = fmaf(ky[2], gv[2][2], fmaf(ky[1], gv[1][2], ky[0] * gv[0][2]));
-        const float u0 = kx[0] * c0, u1 = kx[1] * c1, u2 = kx[2] * c2;
-        const float S = (u0 + u2) + u1;
-        const float gwx = fmaf(-fx, S, u2 - u0);
-        const float r0 = fmaf(kx[2], gv[0][2], fmaf(kx[1], gv[0][1], kx[0] * gv[0][0]));
-        const float r2 = fmaf(kx[2], gv[2][2], fmaf(kx[1], gv[2][1], kx[0] * gv[2][0]));
-        const float gwy = fmaf(-fy, S, fmaf(ky[2], r2, -(ky[0] * r0)));
+        float gwx, gwy;
+        event_dLdw(g, wn, lds, Gi, x, y, v, dt, gwx, gwy);
         if (direct11) {          // theta (1,1,2): Theta is constant, dL/dtheta = sum over all events; no per-pixel image needed.
             // fp32 over the thread's own <= 32 terms (their rounding errors are independent across 10^6 threads and average out:
             // measured 1e-9 relative on the gradient), fp64 from there on
