@@ -82,6 +82,8 @@ SIGNATURES = [
     ('eincm_get_timings_total', C.c_int, [_P, C.POINTER(Timings), C.POINTER(C.c_int64), C.c_int]),
     ('eincm_set_windows_ex', C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int16),
                                        C.POINTER(C.c_int16), _D, _D, _D, C.c_uint32]),
+    ('eincm_set_windows_ptrs', C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.c_uint32]),
     ('eincm_forward_iwe', C.c_int, [_P, _D, C.c_int, C.c_int, C.POINTER(Params), C.c_int]),
     ('eincm_finish_loss_grad', C.c_int, [_P, _D, _D, C.POINTER(Aux)]),
     ('eincm_finish_constants', C.c_int, [_P]),

@@ -882,14 +882,19 @@ void eincm_destroy(eincm_ctx* ctx) {
     delete ctx;
 }
 
-static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* xs, const int16_t* ys,
-                            const double* ts, const double* edges, const double* edge_ts, uint32_t sw_flags) {
+// xs_w / ys_w / ts_w / edges_w: one pointer per window (the caller's own arrays; nothing is concatenated on the host)
+static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* const* xs_w,
+                            const int16_t* const* ys_w, const double* const* ts_w, const double* const* edges_w,
+                            const double* edge_ts, uint32_t sw_flags) {
     if (c && c->pend.active && c->pend.launched)
         return fail(c, EINCM_ERR_STATE, "an asynchronous evaluation is in flight: call eincm_loss_grad_wait first");
     if (!c) return EINCM_ERR_ARG;
     if (n_windows < 1 || n_windows > c->maxB) return fail(c, EINCM_ERR_ARG, "n_windows %d outside 1..%d", n_windows, c->maxB);
     if (n_refs < 1 || n_refs > c->maxR) return fail(c, EINCM_ERR_ARG, "n_refs %d outside 1..%d", n_refs, c->maxR);
-    if (!n_events || !xs || !ys || !ts || !edges || !edge_ts) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (!n_events || !xs_w || !ys_w || !ts_w || !edges_w || !edge_ts) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (n_windows >= 1 && n_windows <= c->maxB)
+        for (int b = 0; b < n_windows; ++b)
+            if (!edges_w[b] || (n_events[b] > 0 && (!xs_w[b] || !ys_w[b] || !ts_w[b]))) return fail(c, EINCM_ERR_ARG, "null pointer argument (window %d)", b);
     HIPCHK(c, hipSetDevice(c->device));
     const int H = c->H, W = c->W;
     int64_t N = 0;
@@ -952,13 +957,21 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         int32_t misc_init[4] = {0, 0, 0x7fffffff, 0x7fffffff};                      // totals[2], err[2]
         HIPCHK(c, hipMemcpyAsync(c->d_bin_misc, misc_init, sizeof misc_init, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_win_blk, win_blk.data(), win_blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_edges_raw, edges, (size_t)n_windows * n_refs * img * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        for (int b = 0; b < n_windows; ++b)
+            HIPCHK(c, hipMemcpyAsync(c->d_edges_raw + (size_t)b * n_refs * img, edges_w[b], (size_t)n_refs * img * sizeof(double), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_edges, dim3(EDGE_PARTS, n_refs, n_windows), dim3(NT), 0, c->stream, g, c->d_edges_raw, c->d_edges, c->d_edge_moments);
         if (nblk > 0) {
             HIPCHK(c, hipMemcpyAsync(c->d_binblocks, blks.data(), blks.size() * sizeof(BinBlock), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->d_raw_x, xs, (size_t)N * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->d_raw_y, ys, (size_t)N * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->d_raw_t, ts, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            int64_t off = 0;
+            for (int b = 0; b < n_windows; ++b) {
+                const size_t nb = (size_t)n_events[b];
+                if (nb > 0) {
+                    HIPCHK(c, hipMemcpyAsync(c->d_raw_x + off, xs_w[b], nb * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+                    HIPCHK(c, hipMemcpyAsync(c->d_raw_y + off, ys_w[b], nb * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+                    HIPCHK(c, hipMemcpyAsync(c->d_raw_t + off, ts_w[b], nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                }
+                off += (int64_t)nb;
+            }
             hipLaunchKernelGGL(k_bin_hist, dim3(nblk), dim3(BIN_NT), g.ntiles * sizeof(uint32_t), c->stream, g, c->d_binblocks, c->d_raw_x, c->d_raw_y,
                                c->d_raw_t, c->d_blockhist, c->d_bin_misc + 2);
         } else {
@@ -980,7 +993,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             int b = 0; int64_t off = e;
             while (b < n_windows - 1 && off >= n_events[b]) { off -= n_events[b]; ++b; }
             return fail(c, EINCM_ERR_ARG, "event %lld of window %d at (x=%d, y=%d) outside the %dx%d sensor", (long long)off, b,
-                        (int)xs[e], (int)ys[e], H, W);
+                        (int)xs_w[b][off], (int)ys_w[b][off], H, W);
         }
         if (misc[3] != 0x7fffffff) {
             const int64_t e = misc[3];
@@ -1042,7 +1055,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     int64_t base = 0;
     for (int b = 0; b < n_windows; ++b) {
         const int64_t n = n_events[b];
-        const int16_t* x = xs + base; const int16_t* y = ys + base; const double* t = ts + base;
+        const int16_t* x = xs_w[b]; const int16_t* y = ys_w[b]; const double* t = ts_w[b];
         std::fill(cnt.begin(), cnt.end(), 0);
         item0_h.push_back((int32_t)items.size());
         for (int64_t i = 0; i < n; ++i) {
@@ -1091,7 +1104,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     for (int b = 0; b < n_windows; ++b) {
         WinConst& wc = c->h_wc[b];
         for (int r = 0; r < n_refs; ++r) {
-            const double* e = edges + ((size_t)b * n_refs + r) * img;
+            const double* e = edges_w[b] + (size_t)r * img;
             float* o = ef.data() + ((size_t)b * n_refs + r) * img;
             double s = 0.0, ss = 0.0;
             for (size_t i = 0; i < img; ++i) { const float f = (float)e[i]; o[i] = f; s += (double)f; ss += (double)f * (double)f; }
@@ -1171,13 +1184,36 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     return rc;
 }
 
+// The concatenated forms: per-window pointers into the caller's arrays.
+static int set_windows_concat(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* xs, const int16_t* ys,
+                              const double* ts, const double* edges, const double* edge_ts, uint32_t flags) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!n_events || !xs || !ys || !ts || !edges || !edge_ts) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (n_windows < 1 || n_windows > c->maxB) return fail(c, EINCM_ERR_ARG, "n_windows %d outside 1..%d", n_windows, c->maxB);
+    std::vector<const int16_t*> xw((size_t)n_windows), yw((size_t)n_windows);
+    std::vector<const double*> tw((size_t)n_windows), ew((size_t)n_windows);
+    int64_t base = 0;
+    const size_t img = (size_t)c->H * c->W;
+    for (int b = 0; b < n_windows; ++b) {
+        xw[b] = xs + base; yw[b] = ys + base; tw[b] = ts + base; ew[b] = edges + (size_t)b * (size_t)std::max(n_refs, 0) * img;
+        base += std::max<int64_t>(n_events[b], 0);
+    }
+    return set_windows_impl(c, n_windows, n_refs, n_events, xw.data(), yw.data(), tw.data(), ew.data(), edge_ts, flags);
+}
+
 int eincm_set_windows(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* xs, const int16_t* ys,
                       const double* ts, const double* edges, const double* edge_ts) {
-    return set_windows_impl(c, n_windows, n_refs, n_events, xs, ys, ts, edges, edge_ts, 0u);
+    return set_windows_concat(c, n_windows, n_refs, n_events, xs, ys, ts, edges, edge_ts, 0u);
 }
 
 int eincm_set_windows_ex(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* xs, const int16_t* ys,
                          const double* ts, const double* edges, const double* edge_ts, uint32_t flags) {
+    return set_windows_concat(c, n_windows, n_refs, n_events, xs, ys, ts, edges, edge_ts, flags);
+}
+
+int eincm_set_windows_ptrs(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* const* xs,
+                           const int16_t* const* ys, const double* const* ts, const double* const* edges, const double* edge_ts,
+                           uint32_t flags) {
     return set_windows_impl(c, n_windows, n_refs, n_events, xs, ys, ts, edges, edge_ts, flags);
 }
 

@@ -103,22 +103,26 @@ class Engine:
         B = len(windows)
         R = len(np.atleast_1d(windows[0][4]))
         n = np.array([len(w[0]) for w in windows], dtype=np.int64)
-        def cat(parts):         # one window (the reference's solver): hand the caller's arrays over as they are, no 120 MB copy at 1e7 events
-            return np.ascontiguousarray(parts[0]) if len(parts) == 1 else np.concatenate(parts)
-        xs = cat([as_int16_coords(w[0], 'xs') for w in windows])
-        ys = cat([as_int16_coords(w[1], 'ys') for w in windows])
-        ts = cat([np.asarray(w[2], dtype=np.float64) for w in windows])
-        edges = np.ascontiguousarray(np.stack([np.asarray(w[3], dtype=np.float64) for w in windows]))
+        # every window's arrays go over as they are (one pointer per window): no host-side concatenation of the batch
+        xs = [np.ascontiguousarray(as_int16_coords(w[0], 'xs')) for w in windows]
+        ys = [np.ascontiguousarray(as_int16_coords(w[1], 'ys')) for w in windows]
+        ts = [np.ascontiguousarray(np.asarray(w[2], dtype=np.float64)) for w in windows]
+        edges = [np.ascontiguousarray(np.asarray(w[3], dtype=np.float64)) for w in windows]
         edge_ts = np.ascontiguousarray(np.stack([np.atleast_1d(np.asarray(w[4], dtype=np.float64)) for w in windows]))
-        if edges.shape != (B, R, self.H, self.W):
-            raise ValueError(f'edges must be (R,{self.H},{self.W}) per window, got {edges.shape[1:]}')
+        for b, e in enumerate(edges):
+            if e.shape != (R, self.H, self.W):
+                raise ValueError(f'edges must be (R,{self.H},{self.W}) per window, got {e.shape} for window {b}')
         if edge_ts.shape != (B, R):
             raise ValueError('every window needs the same number of reference times')
-        if xs.size == 0:
-            xs = np.zeros(1, np.int16); ys = np.zeros(1, np.int16); ts = np.zeros(1, np.float64)
-        rc = self._lib.eincm_set_windows_ex(self._ctx, B, R, n.ctypes.data_as(C.POINTER(C.c_int64)),
-                                            xs.ctypes.data_as(C.POINTER(C.c_int16)), ys.ctypes.data_as(C.POINTER(C.c_int16)),
-                                            _dp(ts), _dp(edges), _dp(edge_ts), L.SW_DEFER_CONSTANTS if defer_constants else 0)
+        for b in range(B):
+            if not (len(xs[b]) == len(ys[b]) == len(ts[b])):
+                raise ValueError(f'window {b}: xs, ys, ts differ in length')
+        one = np.zeros(1, np.int16), np.zeros(1, np.float64)           # a valid address for empty windows
+        def ptrs(arrs, dummy):
+            return (C.c_void_p * B)(*[(a if a.size else dummy).ctypes.data for a in arrs])
+        rc = self._lib.eincm_set_windows_ptrs(self._ctx, B, R, n.ctypes.data_as(C.POINTER(C.c_int64)),
+                                              ptrs(xs, one[0]), ptrs(ys, one[0]), ptrs(ts, one[1]), ptrs(edges, one[1]),
+                                              _dp(edge_ts), L.SW_DEFER_CONSTANTS if defer_constants else 0)
         self._check(rc)
         self.B, self.R = B, R
         self.n_events = n
