@@ -189,3 +189,30 @@ def test_timing_modes_agree_and_do_not_change_results(built_lib):
         assert np.array_equal(res[mode][0], res[False][0]) and np.array_equal(res[mode][1], res[False][1])
     for k in ('splat', 'gather'):                                # kernel durations of a few microseconds: same within 25 % + 2 us
         assert abs(tim[True][k] - tim['dominant'][k]) < 0.25 * tim[True][k] + 2e-3, (k, tim)
+
+
+def test_concatenated_and_per_window_staging_agree(built_lib):
+    """eincm_set_windows_ex (one concatenated array per field, the round-1 form) and eincm_set_windows_ptrs (one pointer per window,
+    what Engine.set_windows uses) stage the same batch: identical values and gradients, an empty window included."""
+    import ctypes as C
+    wins, args = _batch(3, N=15000)
+    args[1] = (args[1][0][:0], args[1][1][:0], args[1][2][:0], args[1][3], args[1][4])          # window 1 has no events
+    th = np.stack([synth.theta_near_truth(50 + b, w, (2, 2)) for b, w in enumerate(wins)])
+    p = engine.make_params(20.0, 35.0, 0.0, 0.0, 3)
+    n_tot = sum(len(a[0]) for a in args)
+    with engine.Engine((96, 128), n_tot, max_refs=3, max_windows=3) as e:
+        e.set_windows(args)
+        v0, g0, _ = e.loss_grad(th, p)
+        n = np.array([len(a[0]) for a in args], dtype=np.int64)
+        xs = np.concatenate([a[0] for a in args]).astype(np.int16); ys = np.concatenate([a[1] for a in args]).astype(np.int16)
+        ts = np.concatenate([a[2] for a in args]).astype(np.float64)
+        edges = np.ascontiguousarray(np.stack([a[3] for a in args]), dtype=np.float64)
+        edge_ts = np.ascontiguousarray(np.stack([a[4] for a in args]), dtype=np.float64)
+        D = C.POINTER(C.c_double)
+        rc = e._lib.eincm_set_windows_ex(e._ctx, 3, 3, n.ctypes.data_as(C.POINTER(C.c_int64)), xs.ctypes.data_as(C.POINTER(C.c_int16)),
+                                         ys.ctypes.data_as(C.POINTER(C.c_int16)), ts.ctypes.data_as(D), edges.ctypes.data_as(D),
+                                         edge_ts.ctypes.data_as(D), 0)
+        assert rc == 0
+        v1, g1, _ = e.loss_grad(th, p)
+    assert np.array_equal(v0, v1) and np.array_equal(g0, g1)
+    assert np.all(np.isfinite(v0))
