@@ -71,7 +71,8 @@ struct eincm_ctx {
     // device-side staging (eincm_binning.hip.h)
     int16_t* d_raw_x = nullptr; int16_t* d_raw_y = nullptr; double* d_raw_t = nullptr;   // (maxN) events as handed over
     BinBlock* d_binblocks = nullptr; int32_t* d_win_blk = nullptr; uint32_t* d_blockhist = nullptr;
-    int32_t* d_tilecount = nullptr; int32_t* d_tilebase = nullptr; int32_t* d_itembase = nullptr; int32_t* d_bin_misc = nullptr;
+    int32_t* d_tilecount = nullptr; int32_t* d_tilebase = nullptr; int32_t* d_itembase = nullptr; int32_t* d_itembase_s = nullptr; int32_t* d_bin_misc = nullptr;
+    bool itembase_valid = false;   // d_itembase / d_itembase_s hold the first segment of every (window, tile) for the staged batch
     double* d_edges_raw = nullptr; double* d_edge_moments = nullptr;
     int64_t max_binblocks = 0;
     bool host_binning = false;
@@ -229,7 +230,7 @@ void multi_ref_weights(int R, double* w) {
 void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_items_s); F(c->d_order); F(c->d_order_s); F(c->d_wins); F(c->d_wins_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
-    F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_acc); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
+    F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_itembase_s); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_acc); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
     F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax); F(c->d_cntmax);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
     F(c->d_divparts); F(c->d_g2parts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
@@ -354,10 +355,15 @@ int clear_accumulators(eincm_ctx* c) {
 }
 
 // theta -> Theta image (+ per-tile velocity bounds) for every window.  theta_dev: (B,h,w,2) on the device or in mapped host memory.
-void launch_theta_image(eincm_ctx* c, int h, int w, bool identity, bool use_arg, const ThetaArg& targ, const double* theta_dev) {
+// with_windows: k_theta also fills the window tables of both segment lists (every theta but the 2-DoF one, whose k_theta_const does)
+void launch_theta_image(eincm_ctx* c, int h, int w, bool identity, bool use_arg, const ThetaArg& targ, const double* theta_dev,
+                        bool with_windows) {
     const Geom& g = c->g;
-    hipLaunchKernelGGL(k_theta, dim3(g.ntiles, g.B), dim3(NT), 0, c->stream, g, h, w, identity ? 1 : 0, use_arg ? 1 : 0, targ,
-                       theta_dev, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_Theta, c->d_tmm);
+    const bool ww = with_windows && c->itembase_valid;
+    launch_timed(c, EINCM_STAGE_THETA, k_theta, dim3(g.ntiles, g.B), dim3(NT), 0, g, h, w, identity ? 1 : 0, use_arg ? 1 : 0, targ,
+                 theta_dev, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_Theta, c->d_tmm, c->d_edge_ts,
+                 c->n_items, c->d_items, ww ? c->d_itembase : nullptr, c->d_wins,
+                 c->n_items_s, c->d_items_s, ww ? c->d_itembase_s : nullptr, c->d_wins_s);
     c->Theta_valid = true;
 }
 
@@ -382,18 +388,18 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
         HIPCHK(c, hipMemcpyAsync(c->d_theta_in, c->h_theta, (size_t)g.B * nth * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
     {
-        StageTimer t(c, EINCM_STAGE_THETA, const_theta && !need_theta_image);
+        StageTimer t(c, EINCM_STAGE_THETA, const_theta ? !need_theta_image : c->itembase_valid);       // one kernel in either case
         const int nwin_threads = (c->n_items + c->n_items_s) * g.R;
         if (const_theta) {
             c->last_theta11.assign(theta_host, theta_host + (size_t)g.B * 2);
             c->Theta_valid = false;
-            if (need_theta_image) launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev);
+            if (need_theta_image) launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev, false);
             launch_timed(c, EINCM_STAGE_THETA, k_theta_const, dim3((std::max(g.B * g.ntiles, nwin_threads) + NT - 1) / NT), dim3(NT), 0, g,
                                use_arg ? 1 : 0, targ, theta_dev, c->d_tmm, c->d_edge_ts, c->n_items, c->d_items, c->d_wins,
                                c->n_items_s, c->d_items_s, c->d_wins_s);
         } else {
-            launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev);
-            if (nwin_threads > 0)
+            launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev, true);
+            if (nwin_threads > 0 && !c->itembase_valid)
                 hipLaunchKernelGGL(k_windows, dim3((nwin_threads + NT - 1) / NT), dim3(NT), 0, c->stream, g, c->d_tmm, c->d_edge_ts,
                                    c->n_items, c->d_items, c->d_wins, c->n_items_s, c->d_items_s, c->d_wins_s);
         }
@@ -815,6 +821,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
         TRY(dalloc(&c->d_tilecount, B * ntiles));
         TRY(dalloc(&c->d_tilebase, B * ntiles));
         TRY(dalloc(&c->d_itembase, B * ntiles));
+        TRY(dalloc(&c->d_itembase_s, B * ntiles));
         TRY(dalloc(&c->d_bin_misc, (size_t)8));
         TRY(dalloc(&c->d_edges_raw, B * R * img));
         TRY(dalloc(&c->d_edge_moments, B * R * EDGE_PARTS * 2));
@@ -1021,12 +1028,12 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
                                c->d_win_item0, c->d_dtmax);
             HIPCHK(c, hipMemcpyAsync(dtmax_h.data(), c->d_dtmax, (size_t)n_windows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             // second segmentation of the same binned events for k_splat
-            hipLaunchKernelGGL(k_bin_tilescan, dim3(1), dim3(1024), 0, c->stream, M, seg_s, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_bin_misc);
+            hipLaunchKernelGGL(k_bin_tilescan, dim3(1), dim3(1024), 0, c->stream, M, seg_s, c->d_tilecount, c->d_tilebase, c->d_itembase_s, c->d_bin_misc);
             HIPCHK(c, hipMemcpyAsync(misc, c->d_bin_misc, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             n_items_s_total = misc[1];
             if (n_items_s_total > c->max_items) return fail(c, EINCM_ERR_ARG, "internal: %d splat segments exceed capacity", n_items_s_total);
-            hipLaunchKernelGGL(k_items, dim3((M + 255) / 256), dim3(256), 0, c->stream, g, seg_s, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_items_s);
+            hipLaunchKernelGGL(k_items, dim3((M + 255) / 256), dim3(256), 0, c->stream, g, seg_s, c->d_tilecount, c->d_tilebase, c->d_itembase_s, c->d_items_s);
             if (n_items_s_total > 0)
                 hipLaunchKernelGGL(k_seg_minmax, dim3(std::min(n_items_s_total, 4096)), dim3(NT), 0, c->stream, n_items_s_total, c->d_items_s, c->d_t);
             HIPCHK(c, hipGetLastError());
@@ -1139,6 +1146,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     HIPCHK(c, hipMemsetAsync(c->d_mask, 0, (size_t)n_windows * img, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->g = g; c->n_items = n_items_total; c->n_items_s = n_items_s_total; c->n_events = N;
+    c->itembase_valid = !c->host_binning && n_items_total > 0 && n_items_s_total > 0;      // both tile scans ran on the device
     c->win_events.assign(n_events, n_events + n_windows);
     if (c->n_items > 0 && !c->host_binning) {     // event mask + most events on one source pixel, per tile from its LDS histogram
         HIPCHK(c, hipMemsetAsync(c->d_cntmax, 0, (size_t)n_windows * sizeof(unsigned), c->stream));
@@ -1404,7 +1412,7 @@ static int ensure_theta_image(eincm_ctx* c) {
     if (rc) return rc;
     memcpy(c->h_theta, c->last_theta11.data(), c->last_theta11.size() * sizeof(double));
     ThetaArg targ{};
-    launch_theta_image(c, 1, 1, false, false, targ, c->h_theta);
+    launch_theta_image(c, 1, 1, false, false, targ, c->h_theta, false);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return EINCM_OK;

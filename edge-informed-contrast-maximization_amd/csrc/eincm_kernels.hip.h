@@ -359,9 +359,15 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
         const int2* __restrict__ rowtap,       // (H) [lo,hi) non-zero range of AH[y,:]
         const int2* __restrict__ coltap,       // (W)
         double* __restrict__ Theta,            // (B,H,W,2)
-        double* __restrict__ tmm)              // (B,ntiles,4) vxmin,vxmax,vymin,vymax
+        double* __restrict__ tmm,              // (B,ntiles,4) vxmin,vxmax,vymin,vymax
+        // window tables of this tile's segments (both segment lists), filled here when itembase_* != nullptr: a workgroup knows its
+        // tile's velocity bounds, and the segments of a (window, tile) are contiguous from itembase[b * ntiles + tile]
+        const double* __restrict__ edge_ts,
+        int n_a, const Item* __restrict__ items_a, const int32_t* __restrict__ itembase_a, Window* __restrict__ wins_a,
+        int n_b, const Item* __restrict__ items_b, const int32_t* __restrict__ itembase_b, Window* __restrict__ wins_b)
 {
     __shared__ double red[4][NWAVE];
+    __shared__ double mm4s[4];
     __shared__ double nanred[NWAVE];
     __shared__ ResampleLds RL;
     __shared__ double2 sth[RS_MAXC * RS_MAXC];      // the coarse cells under this tile
@@ -453,6 +459,21 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
         double* o = tmm + ((size_t)b * g.ntiles + tile) * 4;
         if (nf > 0.0) { a = bq = c = d = NAN; }
         o[0] = a; o[1] = bq; o[2] = c; o[3] = d;
+        mm4s[0] = a; mm4s[1] = bq; mm4s[2] = c; mm4s[3] = d;
+    }
+    if (itembase_a == nullptr) return;           // uniform: the caller fills the window tables elsewhere (k_theta_const / k_windows)
+    __syncthreads();
+    const double mm4[4] = {mm4s[0], mm4s[1], mm4s[2], mm4s[3]};
+    const int idx = b * g.ntiles + tile, last = g.B * g.ntiles - 1;
+    const int a0 = itembase_a[idx], a1 = (idx < last) ? itembase_a[idx + 1] : n_a;
+    const int b0 = itembase_b[idx], b1 = (idx < last) ? itembase_b[idx + 1] : n_b;
+    const int na = (a1 - a0) * g.R, nb = (b1 - b0) * g.R;
+    for (int k = threadIdx.x; k < na + nb; k += NT) {
+        const bool first = k < na;
+        const int kk = first ? k : k - na;
+        const int item = (first ? a0 : b0) + kk / g.R, r = kk % g.R;
+        const Item it = (first ? items_a : items_b)[item];
+        (first ? wins_a : wins_b)[(size_t)item * g.R + r] = item_window(g, it, mm4, edge_ts[it.win * g.R + r]);
     }
 }
 
