@@ -566,8 +566,8 @@ int eval_end_launch(eincm_ctx* c) {
         hipLaunchKernelGGL(k_div, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_parts, c->d_divparts);
     }
     if (ep.want_tv) {
-        StageTimer t(c, EINCM_STAGE_TV);
-        hipLaunchKernelGGL(k_tv, dim3(g.ntiles, g.B), dim3(NT), 0, c->stream, g, c->d_Theta, c->d_mask, c->d_tvg,
+        StageTimer t(c, EINCM_STAGE_TV, true);
+        launch_timed(c, EINCM_STAGE_TV, k_tv, dim3(g.ntiles, g.B), dim3(NT), 0, g, c->d_Theta, c->d_mask, c->d_tvg,
                            c->d_tvparts, full_aux ? 1 : 0);
     }
     const bool direct11 = want_grad && !identity && h == 1 && w == 1;
@@ -588,10 +588,18 @@ int eval_end_launch(eincm_ctx* c) {
             // 44 KB of LDS (G window + i64 accumulators + Theta tile) fit 3 workgroups per CU: 512 threads each keep 24 waves there
             constexpr int NT_TILE = 512;
             if (c->n_items > 0) {
-#define GATHER_ARGS(NTH) dim3(event_grid(c)), dim3(NTH), \
+                // Theta grids / dense theta: the gather walks whichever segment list has the longer segments (its per-workgroup
+                // costs - Theta tile, accumulator clear and flush - want them long even for one window, where the 2-DoF gather
+                // wants 4096); nothing downstream depends on the list (the per-segment partials are a 2-DoF matter).
+                const bool use_s = !direct11 && c->seg_s_used > c->seg_used && c->n_items_s > 0;
+                const int n_g = use_s ? c->n_items_s : c->n_items;
+                const Item* items_g = use_s ? c->d_items_s : c->d_items;
+                const Window* wins_g = use_s ? c->d_wins_s : c->d_wins;
+                const int32_t* order_g = use_s ? c->d_order_s : c->d_order;
+#define GATHER_ARGS(NTH) dim3(use_s ? splat_grid(c) : event_grid(c)), dim3(NTH), \
                     g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), \
-                    g, c->n_items, c->d_items, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, c->d_wins, c->d_gTheta, \
-                    direct11 ? 1 : 0, c->d_g11, c->d_wc, c->d_gmax, direct11 ? THETA_CONST : THETA_TILE, c->d_order
+                    g, n_g, items_g, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, wins_g, c->d_gTheta, \
+                    direct11 ? 1 : 0, c->d_g11, c->d_wc, c->d_gmax, direct11 ? THETA_CONST : THETA_TILE, order_g
                 if (direct11) {
                     launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT>, GATHER_ARGS(NT));
                     c->g11_per_item = g.R;
@@ -926,11 +934,13 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     //   k_gather: x >= 4000 (8 windows x 10^6 events, one window of 10^7): 16384 (96.9 -> 91.7 us, 167 -> 140 us);
     //             x < 1000 (one 10^6-event window): 4096 (22.8 us against 25.5 with 8192 and 41 with 16384); else 8192.
     //   k_splat:  bound by LDS atomics, it gains nothing beyond 8192 (108 us at 8192 and 16384, 122 at 4096, 186 at 2048 on the
-    //             8-window batch); 4096 only where the launch would not fill the chip.
+    //             8-window batch) and loses nothing with it on a single window (22.7 vs 23.5 us; theta grids 22.3 vs 24.5).
+    //   theta grids / dense theta: the gather walks the list with the longer segments (one 10^6-event window at 16x16: 35.8 us
+    //             with 4096, 30.3 with 8192, 28.6 with 16384; the 8-window batch 157 / 144 / 139 with 8192 / 16384 / 32768).
     const double x_wg = ((double)N / 8192.0 + 0.5 * n_windows * g.ntiles) * n_refs;
     int seg = c->seg > 0 ? c->seg : (x_wg >= 4000.0 ? 16384 : (x_wg < 1000.0 ? 4096 : 8192));
     c->seg_used = seg;
-    int seg_s = c->seg_s > 0 ? c->seg_s : (x_wg >= 1000.0 ? 8192 : 4096);
+    int seg_s = c->seg_s > 0 ? c->seg_s : 8192;
     c->seg_s_used = seg_s;
     if (!c->chunk_fixed) c->chunk = std::max(4096, std::min(seg_s, MAX_CHUNK));     // single-chunk segments: no f32 commit pass
     const size_t img = (size_t)H * W;
