@@ -947,7 +947,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     const double x_wg = ((double)N / 8192.0 + 0.5 * n_windows * g.ntiles) * n_refs;
     int seg = c->seg > 0 ? c->seg : (x_wg >= 4000.0 ? 16384 : (x_wg < 1000.0 ? 4096 : 8192));
     c->seg_used = seg;
-    int seg_s = c->seg_s > 0 ? c->seg_s : 8192;
+    int seg_s = c->seg_s > 0 ? c->seg_s : (x_wg >= 400.0 ? 8192 : 4096);     // one window at R = 1: 4096 (0.066 vs 0.075 ms per evaluation)
     c->seg_s_used = seg_s;
     if (!c->chunk_fixed) c->chunk = std::max(4096, std::min(seg_s, MAX_CHUNK));     // single-chunk segments: no f32 commit pass
     const size_t img = (size_t)H * W;
