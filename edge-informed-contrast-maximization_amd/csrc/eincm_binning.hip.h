@@ -136,6 +136,37 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_scatter(Geom g, const BinBlock* 
     }
 }
 
+// Re-deal the events inside every block of 256 consecutive events of a tile (the 256 events the threads of an event-kernel workgroup
+// take in one trip): sorted by source pixel, then dealt round-robin to the four 64-event groups, so that the events a wavefront
+// handles together come from different source pixels.  Events of one source pixel at nearby times land on one destination pixel,
+// and LDS atomics are slower on shared destinations (profiles/r02/splat_bound_experiment.txt): k_splat gains 4-6 %.  The
+// permutation is a function of the block's content alone (keys are unique: pixel, then position), so re-staging reproduces it;
+// segments are multiples of 256 events from the tile's start, so no event changes segment.  A trailing partial block keeps its order.
+// grid (B * ntiles) workgroups of 256 threads.
+__global__ __launch_bounds__(256) void k_spread(Geom g, const int32_t* __restrict__ tilecount, const int32_t* __restrict__ tilebase,
+                                                uint32_t* __restrict__ ev_xy, double* __restrict__ ev_t)
+{
+    __shared__ uint32_t keys[256];
+    const int idx = blockIdx.x;
+    const int cnt = tilecount[idx], base = tilebase[idx];
+    const int t = threadIdx.x;
+    for (int b0 = 0; b0 + 256 <= cnt; b0 += 256) {
+        const uint32_t xy = ev_xy[base + b0 + t];
+        const double tm = ev_t[base + b0 + t];
+        // pixel inside the 32x32 tile (10 bits) above the position in the block (8 bits)
+        const uint32_t key = (((xy >> 11) & (31u << 5)) | (xy & 31u)) << 8 | (uint32_t)t;
+        __syncthreads();                                  // the previous block's keys are no longer read
+        keys[t] = key;
+        __syncthreads();
+        int rank = 0;
+#pragma unroll 8
+        for (int k = 0; k < 256; ++k) rank += (keys[k] < key) ? 1 : 0;       // broadcast reads
+        const int pos = (rank & 3) * 64 + (rank >> 2);
+        ev_xy[base + b0 + pos] = xy;                      // every thread has read its event: the block-local permutation is safe in place
+        ev_t[base + b0 + pos] = tm;
+    }
+}
+
 // thread per (window, tile): emit its segments
 __global__ void k_items(Geom g, int seg, const int32_t* __restrict__ tilecount, const int32_t* __restrict__ tilebase,
                         const int32_t* __restrict__ itembase, Item* __restrict__ items)

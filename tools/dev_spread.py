@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 engine = importlib.import_module('edge-informed-contrast-maximization_amd.engine')
 synth = importlib.import_module('edge-informed-contrast-maximization_amd.synth')
 H, W, N, R, B = 260, 346, 1000000, 5, int(os.environ.get('B', '8'))
+HW = tuple(int(v) for v in os.environ.get('THETA', '1x1').split('x'))
 TS = 32
 
 
@@ -45,7 +46,7 @@ def spread(xs, ys, ts, blk):
 
 
 def run(wins, th, label):
-    p = engine.make_params(20., 35., 0., 0., 4)
+    p = engine.make_params(20., 35., 0., 0., 4 if HW == (1, 1) else 1)
     with engine.Engine((H, W), B * N, max_refs=R, max_windows=B, timing=True) as e:
         e.set_windows(wins)
         t_end = time.perf_counter() + 0.3
@@ -62,7 +63,7 @@ def run(wins, th, label):
 
 def main():
     raw = [synth.make_window(b, (H, W), N, R, flow='constant', flow_mag=20.0) for b in range(B)]
-    th = np.stack([synth.theta_near_truth(b, w, (1, 1)) for b, w in enumerate(raw)])
+    th = np.stack([synth.theta_near_truth(b, w, HW) for b, w in enumerate(raw)])
     run([(w['xs'], w['ys'], w['ts'], w['edges'], w['edge_ts']) for w in raw], th, 'time order')
     for blk in (256, 1024):
         wins = []
