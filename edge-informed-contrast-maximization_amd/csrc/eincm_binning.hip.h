@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_spread(Geom g, const int32_t* __restric
         const uint32_t xy = ev_xy[base + b0 + t];
         const double tm = ev_t[base + b0 + t];
         // pixel inside the 32x32 tile (10 bits) above the position in the block (8 bits)
-        const uint32_t key = (((xy >> 11) & (31u << 5)) | (xy & 31u)) << 8 | (uint32_t)t;
+        const uint32_t key = (((xy >> 11) & (31u << 5)) | (xy & 31u)) << 8 | (uint32_t)t;      // (a Morton key of the pixel measured the same)
         __syncthreads();                                  // the previous block's keys are no longer read
         keys[t] = key;
         __syncthreads();
