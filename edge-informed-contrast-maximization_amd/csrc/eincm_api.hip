@@ -1037,7 +1037,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(BIN_NT), g.ntiles * sizeof(uint32_t), c->stream, g, c->d_binblocks, c->d_raw_x, c->d_raw_y,
                                c->d_raw_t, c->d_blockhist, c->d_tilebase, c->d_xy, c->d_t);
             if (!getenv("EINCM_NO_SPREAD"))
-                hipLaunchKernelGGL(k_spread, dim3(M), dim3(256), 0, c->stream, g, c->d_tilecount, c->d_tilebase, c->d_xy, c->d_t);
+                hipLaunchKernelGGL(k_spread, dim3(M, SPREAD_Y), dim3(256), 0, c->stream, g, c->d_tilecount, c->d_tilebase, c->d_xy, c->d_t);
             hipLaunchKernelGGL(k_items, dim3((M + 255) / 256), dim3(256), 0, c->stream, g, seg, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_items);
             if (n_items_total > 0)
                 hipLaunchKernelGGL(k_seg_minmax, dim3(std::min(n_items_total, 4096)), dim3(NT), 0, c->stream, n_items_total, c->d_items, c->d_t);

@@ -142,15 +142,16 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_scatter(Geom g, const BinBlock* 
 // and LDS atomics are slower on shared destinations (profiles/r02/splat_bound_experiment.txt): k_splat gains 4-6 %.  The
 // permutation is a function of the block's content alone (keys are unique: pixel, then position), so re-staging reproduces it;
 // segments are multiples of 256 events from the tile's start, so no event changes segment.  A trailing partial block keeps its order.
-// grid (B * ntiles) workgroups of 256 threads.
+// grid (B * ntiles, SPREAD_Y) workgroups of 256 threads: the blocks of a tile are dealt round-robin to SPREAD_Y workgroups.
+constexpr int SPREAD_Y = 16;
 __global__ __launch_bounds__(256) void k_spread(Geom g, const int32_t* __restrict__ tilecount, const int32_t* __restrict__ tilebase,
                                                 uint32_t* __restrict__ ev_xy, double* __restrict__ ev_t)
 {
-    __shared__ uint32_t keys[256];
+    __shared__ __attribute__((aligned(16))) uint32_t keys[256];
     const int idx = blockIdx.x;
     const int cnt = tilecount[idx], base = tilebase[idx];
     const int t = threadIdx.x;
-    for (int b0 = 0; b0 + 256 <= cnt; b0 += 256) {
+    for (int b0 = blockIdx.y * 256; b0 + 256 <= cnt; b0 += 256 * gridDim.y) {
         const uint32_t xy = ev_xy[base + b0 + t];
         const double tm = ev_t[base + b0 + t];
         // pixel inside the 32x32 tile (10 bits) above the position in the block (8 bits)
@@ -159,8 +160,12 @@ __global__ __launch_bounds__(256) void k_spread(Geom g, const int32_t* __restric
         keys[t] = key;
         __syncthreads();
         int rank = 0;
+        const uint4* k4 = reinterpret_cast<const uint4*>(keys);
 #pragma unroll 8
-        for (int k = 0; k < 256; ++k) rank += (keys[k] < key) ? 1 : 0;       // broadcast reads
+        for (int k = 0; k < 64; ++k) {                    // broadcast reads, four keys each
+            const uint4 q = k4[k];
+            rank += (q.x < key ? 1 : 0) + (q.y < key ? 1 : 0) + (q.z < key ? 1 : 0) + (q.w < key ? 1 : 0);
+        }
         const int pos = (rank & 3) * 64 + (rank >> 2);
         ev_xy[base + b0 + pos] = xy;                      // every thread has read its event: the block-local permutation is safe in place
         ev_t[base + b0 + pos] = tm;
