@@ -127,6 +127,10 @@ struct eincm_ctx {
     int ring_size = 1;             // EV_RING in the dominant mode, 1 otherwise (read out at once)
     int ring_lo = 0, ring_n = 0;   // finished evaluations whose events have not been read yet: slots ring_lo .. ring_lo + ring_n - 1
     int ring_cur = 0;              // slot of the evaluation in flight
+    static constexpr int GRAD_PIECES = 4;
+    hipEvent_t ev_piece[GRAD_PIECES] = {};   // dense gradients come back in pieces; the host scans piece k while piece k + 1 crosses PCIe
+    int n_pieces = 0;              // pieces of the evaluation in flight (0: the gradient came with the results / in one copy)
+    size_t piece_len = 0;
     int attach_stage = -1;         // EINCM_CF_TIMING: the single-kernel stage whose launch takes its events along (StageTimer)
     bool time_splat = true, time_gather = true;   // EINCM_CF_TIMING_DOMINANT: which event kernels carry start / stop events (eincm_set_timed_kernels)
     bool have_events = false;
@@ -243,6 +247,7 @@ void free_all(eincm_ctx* c) {
             for (int i = 0; i <= EINCM_N_STAGES; ++i)
                 for (int e = 0; e < 2; ++e)
                     if (c->ev[k][i][e]) { (void)hipEventDestroy(c->ev[k][i][e]); c->ev[k][i][e] = nullptr; }
+        for (int k = 0; k < eincm_ctx::GRAD_PIECES; ++k) if (c->ev_piece[k]) { (void)hipEventDestroy(c->ev_piece[k]); c->ev_piece[k] = nullptr; }
         c->have_events = false;
     }
     if (c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
@@ -641,8 +646,23 @@ int eval_end_launch(eincm_ctx* c) {
         }
     }
     HIPCHK(c, hipGetLastError());
+    c->n_pieces = 0;
     if (zero_copy_out) {
         // nothing to copy
+    } else if (want_grad && (size_t)g.B * nth >= ((size_t)1 << 17)) {
+        // a dense gradient (4.9 MB at 480x640): in pieces, an event behind each, so that eval_end_collect hands piece k over
+        // (copy + finite scan on the host) while piece k + 1 is still crossing PCIe
+        HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal), hipMemcpyDeviceToHost, c->stream));
+        const size_t total = (size_t)g.B * nth;
+        c->piece_len = (total + eincm_ctx::GRAD_PIECES - 1) / eincm_ctx::GRAD_PIECES;
+        for (int k = 0; k < eincm_ctx::GRAD_PIECES; ++k) {
+            const size_t off = (size_t)k * c->piece_len;
+            if (off >= total) break;
+            const size_t n = std::min(c->piece_len, total - off);
+            HIPCHK(c, hipMemcpyAsync(c->h_grad + off, c->d_grad + off, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipEventRecord(c->ev_piece[k], c->stream));
+            c->n_pieces = k + 1;
+        }
     } else if (want_grad && g.B == c->maxB) {      // outs and grad are contiguous: one copy
         HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal) + (size_t)g.B * nth * sizeof(double),
                                  hipMemcpyDeviceToHost, c->stream));
@@ -665,6 +685,24 @@ int eval_end_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) 
     const size_t nth = (size_t)c->pend.h * c->pend.w * 2;
     // The stream is drained before ANY return: the kernels in flight read the pinned theta staging buffer and write the pinned
     // result block, so the context must not look idle (and accept the next theta) while they run.
+    bool piece_bad = false;
+    if (c->n_pieces > 0 && want_grad && grad) {
+        const size_t total = (size_t)g.B * nth;
+        for (int k = 0; k < c->n_pieces; ++k) {
+            if (hipEventSynchronize(c->ev_piece[k]) != hipSuccess) break;      // the stream sync below reports the error
+            const size_t off = (size_t)k * c->piece_len, n = std::min(c->piece_len, total - off);
+            const double* __restrict__ src = c->h_grad + off;
+            double* __restrict__ dst = grad + off;
+            uint64_t bad = 0;
+            for (size_t i = 0; i < n; ++i) {
+                uint64_t u;
+                memcpy(&u, src + i, sizeof u);
+                dst[i] = src[i];
+                bad |= (uint64_t)((u & 0x7ff0000000000000ull) == 0x7ff0000000000000ull);
+            }
+            piece_bad = piece_bad || bad != 0;
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->pend.active = false; c->pend.launched = false;
     if (want_grad && !grad) return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
@@ -686,7 +724,8 @@ int eval_end_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) 
         }
         if (o.nonfinite != 0.0) nonfinite = true;
     }
-    if (want_grad) {
+    if (piece_bad) nonfinite = true;
+    if (want_grad && c->n_pieces == 0) {
         // copy out and look for NaN/Inf in the same pass; an integer OR-reduction over the exponent bits vectorises, an
         // early-exit std::isfinite loop does not (0.6 ms of a 1.8 ms dense-theta evaluation at 480x640)
         const size_t n = (size_t)g.B * nth;
@@ -884,6 +923,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_theta), B * img * 2 * sizeof(double), hipHostMallocDefault));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_wc), B * sizeof(WinConst), hipHostMallocDefault));
     c->have_events = true;
+    for (int k = 0; k < eincm_ctx::GRAD_PIECES; ++k) TRY(hipEventCreateWithFlags(&c->ev_piece[k], hipEventDisableTiming));
     c->ring_size = (flags & EINCM_CF_TIMING_DOMINANT) && !(flags & EINCM_CF_TIMING) ? eincm_ctx::EV_RING : 1;
     if (flags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT))
         for (int k = 0; k < c->ring_size; ++k)
