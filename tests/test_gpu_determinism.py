@@ -74,3 +74,29 @@ def test_scipy_bfgs_solves_are_identical(built_lib):
     losses.clear_engine_cache()
     for x, f, it in outs[1:]:
         assert np.array_equal(x, outs[0][0]) and f == outs[0][1] and it == outs[0][2]
+
+
+def test_event_order_inside_a_tile_only_moves_roundings(built_lib, monkeypatch):
+    """Staging re-deals the events of every 256-event block of a tile over the block's four wavefront groups (k_spread, for the LDS atomic
+    unit's sake).  Integer accumulation makes the images independent of the order of the events: the IWE and the count images are
+    bit-identical with and without the re-deal, the loss therefore too; only the gradient's per-thread partial sums may round differently."""
+    H, W, N, R = 260, 346, 300_000, 3
+    win = synth.make_window(33, (H, W), N, R, flow='constant', flow_mag=15.0)
+    out = {}
+    for hw, lvl in (((1, 1), 4), ((8, 8), 1)):
+        th = synth.theta_near_truth(33, win, hw)
+        p = engine.make_params(20.0, 35.0, 0.0, 0.0, lvl)
+        for mode in ('redeal', 'time_order'):
+            if mode == 'time_order':
+                monkeypatch.setenv('EINCM_NO_SPREAD', '1')
+            else:
+                monkeypatch.delenv('EINCM_NO_SPREAD', raising=False)
+            with engine.Engine((H, W), N, max_refs=R) as eng:
+                eng.set_window(*win_args(win))
+                v, g, _ = eng.loss_grad(th, p)
+                out[mode] = (v.copy(), g.copy(), eng.iwes().copy(), eng.count_images())
+        a, b = out['redeal'], out['time_order']
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(a[0], b[0]), (a[0], b[0])
+        np.testing.assert_allclose(a[1], b[1], rtol=0, atol=2e-6 * np.abs(b[1]).max())
+    monkeypatch.delenv('EINCM_NO_SPREAD', raising=False)
