@@ -255,15 +255,15 @@ def bench_windows(a):
         eval_bytes = B * algorithmic_bytes(N, R, H, W, dense)
         roof = dict(dominant)
         roof.update({'bound': 'hbm',
-                     'bound_note': 'priced against HBM as the contract asks; the kernels are NOT HBM-bound at these sizes: PMC shows the VALU '
-                                   'pipe ~90-100 % busy in both event kernels and k_splat at ~92 % of the measured ds_add_u32 rate '
-                                   f'(profiles/{ROUND}/, DESIGN.md section 6)',
+                     'bound_note': 'priced against HBM as the contract asks; the kernels are NOT HBM-bound at these sizes: k_splat is bound by the '
+                                   'LDS atomic unit (ablation: deleting its arithmetic leaves its time unchanged), k_gather by VALU issue '
+                                   f'(profiles/{ROUND}/splat_bound_experiment.txt, DESIGN.md section 4.2)',
                      'event_kernels': kern,
                      'lds_atomic_lane_ops_per_clk_per_cu': (9.0 * B * N * R / (kern['k_splat']['avg_launch_ms'] * 1e-3) / 256 / 2.4e9)
                      if kern['k_splat']['avg_launch_ms'] > 0 else 0.0,
-                     'lds_atomic_peak_lane_ops_per_clk_per_cu': [4.8, 7.4],
-                     'lds_atomic_note': '9 ds_add_u32 per warped event; peak = tools/lds_atomic_bench.hip (clustered, distinct addresses), '
-                                        'profiles/r01/lds_atomic_microbench.txt'})
+                     'lds_atomic_peak_lane_ops_per_clk_per_cu': [5.9, 7.4],
+                     'lds_atomic_note': '9 ds_add_u32 per warped event; peak = tools/lds_atomic_bench2.hip with the splat\'s own tap pattern '
+                                        f'(destinations on 300 sites, uniform destinations), profiles/{ROUND}/splat_bound_experiment.txt'})
         out = {
             'metric': 'warped-events/sec/GPU + loss+grad eval ms, 1e6 events @ 346x260',
             'value': value, 'unit': 'warped-events/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,

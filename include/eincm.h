@@ -50,7 +50,8 @@ extern "C" {
                                       TV at any gamma (losses.py:75), FWL (losses.py:84) */
 
 /* eincm_create flags */
-#define EINCM_CF_TIMING     1u     /* bracket every kernel with HIP events (eincm_get_timings); costs ~10 % of a step */
+#define EINCM_CF_TIMING     1u     /* every stage timed with HIP events (eincm_get_timings): attached to the launch where a stage is one
+                                     * kernel, marker events otherwise and around the whole evaluation; costs ~13 % of a step */
 #define EINCM_CF_TIMING_DOMINANT 2u /* the two event kernels (k_splat, k_gather) are launched with their own start / stop events
                                      * (hipExtLaunchKernelGGL: no marker packets on the stream) and the events are read when the
                                      * timings are asked for, not after every evaluation; total_ms stays 0 in this mode.
