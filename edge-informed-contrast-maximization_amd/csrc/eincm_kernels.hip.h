@@ -1188,9 +1188,13 @@ __device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, cons
     int irx, iry; float fx, fy;
     warp_axis(x, v.x, dt, irx, fx);
     warp_axis(y, v.y, dt, iry, fy);
-    f2v km, k0, kp;
-    taps3x2(fx, fy, INV_2PI, km, k0, kp);
-    const float kx[3] = {km.x, k0.x, kp.x}, ky[3] = {km.y, k0.y, kp.y};
+    // taps k(d) = e0 * (a, 1, b) per axis with e0 = exp(-f^2/2), a = exp(-1/2 - f), b = exp(-1/2 + f): the common factor e0x e0y / (2 pi)
+    // is applied once at the end, and the centre column / row needs no multiplication at all
+    constexpr float L2E = 1.4426950408889634f;
+    const float epx = __builtin_amdgcn_exp2f(fx * L2E), epy = __builtin_amdgcn_exp2f(fy * L2E);
+    const float ax = EXP_M05 * __builtin_amdgcn_rcpf(epx), bx = EXP_M05 * epx;
+    const float ay = EXP_M05 * __builtin_amdgcn_rcpf(epy), by = EXP_M05 * epy;
+    const float scale = __builtin_amdgcn_exp2f(fmaf(fx, fx, fy * fy) * (-0.5f * L2E)) * INV_2PI;
     float gv[3][3];
     const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;
     if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
@@ -1221,16 +1225,16 @@ __device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, cons
     // d k(d)/dw = k(d) ((d - 1) - f) on either axis (d = 0, 1, 2 the tap index), so with S = sum_dy sum_dx Ky[dy] Kx[dx] G[dy][dx]
     //   dL/dwx = sum_dx Kx[dx] ((dx - 1) - fx) c[dx] = (Kx[2] c[2] - Kx[0] c[0]) - fx S,   c[dx] = sum_dy Ky[dy] G[dy][dx]
     //   dL/dwy = (Ky[2] r[2] - Ky[0] r[0]) - fy S,                                         r[dy] = sum_dx Kx[dx] G[dy][dx]
-    // 25 multiply-adds per event (the weighted-tap form W[d] = K[d] ((d - 1) - f) took 36, the tap-by-tap form 42)
-    const float c0 = fmaf(ky[2], gv[2][0], fmaf(ky[1], gv[1][0], ky[0] * gv[0][0]));
-    const float c1 = fmaf(ky[2], gv[2][1], fmaf(ky[1], gv[1][1], ky[0] * gv[0][1]));
-    const float c2 = fmaf(ky[2], gv[2][2], fmaf(ky[1], gv[1][2], ky[0] * gv[0][2]));
-    const float u0 = kx[0] * c0, u1 = kx[1] * c1, u2 = kx[2] * c2;
-    const float S = (u0 + u2) + u1;
-    gwx = fmaf(-fx, S, u2 - u0);
-    const float r0 = fmaf(kx[2], gv[0][2], fmaf(kx[1], gv[0][1], kx[0] * gv[0][0]));
-    const float r2 = fmaf(kx[2], gv[2][2], fmaf(kx[1], gv[2][1], kx[0] * gv[2][0]));
-    gwy = fmaf(-fy, S, fmaf(ky[2], r2, -(ky[0] * r0)));}
+    // 22 multiply-adds per event with the normalised taps above (the weighted-tap form W[d] = K[d] ((d - 1) - f) took 36, the tap-by-tap form 42)
+    const float c0 = fmaf(by, gv[2][0], fmaf(ay, gv[0][0], gv[1][0]));
+    const float c1 = fmaf(by, gv[2][1], fmaf(ay, gv[0][1], gv[1][1]));
+    const float c2 = fmaf(by, gv[2][2], fmaf(ay, gv[0][2], gv[1][2]));
+    const float u0 = ax * c0, u2 = bx * c2;
+    const float S = (u0 + u2) + c1;
+    gwx = scale * fmaf(-fx, S, u2 - u0);
+    const float r0 = fmaf(bx, gv[0][2], fmaf(ax, gv[0][0], gv[0][1]));
+    const float r2 = fmaf(bx, gv[2][2], fmaf(ax, gv[2][0], gv[2][1]));
+    gwy = scale * fmaf(-fy, S, fmaf(by, r2, -(ay * r0)));}
 
 // ------------------------------------------------------------------------------------------------
 // k_gather: reverse of the splat.  grid as k_splat (block_to_work).  For every event of the segment and this reference time:

@@ -73,7 +73,7 @@ def main():
         # The source unrolls the event loop x3 (k_splat: renamed-register pipeline; k_gather: #pragma unroll 2 + remainder), so the
         # common-case blocks come in repeating groups; the MIDDLE group is the steady state.
         #   k_splat : [loads + fp64 warp + tap math (4 v_exp_f32)] [9 products + 9 ds_add_u32]
-        #   k_gather: [loads + fp64 warp (>= 3 global_load)] [window reads (>= 6 ds_read)] [tap math + combination (4 v_exp_f32)]
+        #   k_gather: [loads + fp64 warp (>= 3 global_load)] [window reads (>= 6 ds_read)] [tap math + combination (3 v_exp_f32 + 2 v_rcp_f32)]
         if key.startswith('k_splat'):
             groups, cur = [], []
             for n, ops in bl:
@@ -90,7 +90,7 @@ def main():
                     cur, stage = [(n, ops)], 1
                 elif stage == 1 and has(ops, 'ds_read', 6):
                     cur.append((n, ops)); stage = 2
-                elif stage == 2 and has(ops, 'v_exp_f32', 4):
+                elif stage == 2 and has(ops, 'v_exp_f32', 3):
                     cur.append((n, ops)); stage = 3
                 elif stage == 3:
                     cur.append((n, ops)); groups.append(cur); cur, stage = [], 0
