@@ -1191,10 +1191,11 @@ __device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, cons
     // taps k(d) = e0 * (a, 1, b) per axis with e0 = exp(-f^2/2), a = exp(-1/2 - f), b = exp(-1/2 + f): the common factor e0x e0y / (2 pi)
     // is applied once at the end, and the centre column / row needs no multiplication at all
     constexpr float L2E = 1.4426950408889634f;
-    const float epx = __builtin_amdgcn_exp2f(fx * L2E), epy = __builtin_amdgcn_exp2f(fy * L2E);
-    const float ax = EXP_M05 * __builtin_amdgcn_rcpf(epx), bx = EXP_M05 * epx;
-    const float ay = EXP_M05 * __builtin_amdgcn_rcpf(epy), by = EXP_M05 * epy;
-    const float scale = __builtin_amdgcn_exp2f(fmaf(fx, fx, fy * fy) * (-0.5f * L2E)) * INV_2PI;
+    // the constant factors ride in the exponents: b = 2^(f log2e - log2e/2), a = e^-1 / b, scale = 2^(-(fx^2 + fy^2) log2e/2 - log2(2 pi))
+    constexpr float EXP_M1 = 0.36787944117144233f, LOG2_INV_2PI = -2.651496129472319f;
+    const float bx = __builtin_amdgcn_exp2f(fmaf(fx, L2E, -0.5f * L2E)), by = __builtin_amdgcn_exp2f(fmaf(fy, L2E, -0.5f * L2E));
+    const float ax = EXP_M1 * __builtin_amdgcn_rcpf(bx), ay = EXP_M1 * __builtin_amdgcn_rcpf(by);
+    const float scale = __builtin_amdgcn_exp2f(fmaf(fmaf(fx, fx, fy * fy), -0.5f * L2E, LOG2_INV_2PI));
     float gv[3][3];
     const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;
     if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
