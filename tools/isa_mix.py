@@ -13,7 +13,7 @@ CLASSES = OrderedDict([
     ('fp64 (add/mul/fma/rndne/cvt to or from f64)', re.compile(r'^v_(add|mul|fma|rndne|fract|min|max)_f64|^v_cvt_(f64_|[a-z0-9]+_f64)')),
     ('transcendental (exp/rcp/rsq/log/sqrt)', re.compile(r'^v_(exp|rcp|rsq|log|sqrt)_f32')),
     ('packed fp32 (v_pk_*)', re.compile(r'^v_pk_')),
-    ('fp32 arithmetic', re.compile(r'^v_(add|sub|subrev|mul|fma|fmac|mac|mad|max|min|med3|rndne|fract)_f32|^v_(max3|min3)_f32')),
+    ('fp32 arithmetic', re.compile(r'^v_(add|sub|subrev|mul|fma|fmac|fmaak|fmamk|mac|mad|max|min|med3|rndne|fract)_f32|^v_(max3|min3)_f32')),
     ('convert (fp32 <-> int, no f64)', re.compile(r'^v_cvt_')),
     ('integer / address / select / move', re.compile(r'^v_(add|sub|subrev|mul|mad|lshl|lshr|ashr|and|or|xor|bfe|bfi|cndmask|mov|add3|lshl_add|lshl_or|and_or|or3|mad_u|mul_i|mul_u|min|max|med3|cmp|cmpx|readfirstlane|readlane|writelane|perm|alignbit|mbcnt|accvgpr)')),
     ('LDS (ds_*)', re.compile(r'^ds_')),
