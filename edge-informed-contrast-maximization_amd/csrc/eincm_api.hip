@@ -348,7 +348,7 @@ void segment_lengths(const std::vector<int32_t>& tilecount, int seg, std::vector
 unsigned event_grid(const eincm_ctx* c) { return (unsigned)(((c->n_items + NXCD - 1) / NXCD) * NXCD * c->g.R); }
 unsigned splat_grid(const eincm_ctx* c) { return (unsigned)(((c->n_items_s + NXCD - 1) / NXCD) * NXCD * c->g.R); }
 
-// Every cross-workgroup accumulator (u32 IWE stack, i64 dL/dTheta, i64 coarse cells) is zero between evaluations because its
+// Every cross-workgroup accumulator (u64 IWE stack, i64 dL/dTheta, i64 coarse cells) is zero between evaluations because its
 // consumer clears it.  If a forward half was launched and never consumed (error between the two halves), clear them here.
 int clear_accumulators(eincm_ctx* c) {
     const size_t img = (size_t)c->H * c->W;
@@ -372,7 +372,7 @@ void launch_theta_image(eincm_ctx* c, int h, int w, bool identity, bool use_arg,
     c->Theta_valid = true;
 }
 
-// Launch the forward half: theta -> Theta -> u32 IWE accumulator.
+// Launch the forward half: theta -> Theta -> u64 IWE accumulator.
 // need_theta_image: somebody will read d_Theta (TV term); 2-DoF evaluations otherwise skip the image altogether.
 int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_image, const double* theta_host) {
     const Geom& g = c->g;
@@ -559,7 +559,7 @@ int eval_end_launch(eincm_ctx* c) {
         StageTimer t(c, EINCM_STAGE_STATS, g2_from_imgrad && g.ntiles >= NSPART);
         // Gradient evaluations with the grad-mag contrast take the contrast energy from k_imgrad (which computes the Scharr
         // images anyway), so the statistics are a pure streaming reduction with NSPART fat partials per image.
-        // Either way the statistics pass is the consumer of the u32 accumulator: it leaves the fp32 IWE stack in d_iwe and the
+        // Either way the statistics pass is the consumer of the u64 accumulator: it leaves the fp32 IWE stack in d_iwe and the
         // accumulator zero again.
         if (g2_from_imgrad && g.ntiles >= NSPART) {
             g.nparts = NSPART;

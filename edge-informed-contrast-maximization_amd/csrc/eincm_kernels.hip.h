@@ -11,10 +11,10 @@
 //   k_tv      masked-flow total variation + its (unscaled) gradient image           [regularizers.py:14-38]
 //   k_project adjoint resample dL/dTheta -> dL/dtheta                               [reverse of theta_utils.py:25-35]
 //   k_final   scalar assembly of the loss, aux and the final gradient               [losses.py:176-203]
-// Events are binned once per window by 32x32 SOURCE tile (time order kept inside a tile) and cut into
-// work items of <= chunk events; because Theta is smooth and an item spans a known time range, the
-// destinations of an item fall in a small bounding box that lives in LDS (u32 fixed-point ds_add), so HBM sees one
-// coalesced row-wise flush per item instead of 9 scattered atomics per warped event.
+// Events are binned once per window by 32x32 SOURCE tile (time order, then re-dealt by source pixel inside blocks of 256: k_spread)
+// and cut into segments; because Theta is smooth and a segment spans a known time range, the destinations of a segment fall in a
+// small bounding box that lives in LDS (u32 fixed-point ds_add), so HBM sees one coalesced flush per segment and reference time
+// instead of 9 scattered atomics per warped event.
 //
 // Every accumulation that crosses workgroups is INTEGER (fixed point): the IWE stack is summed as u64 at the fixed scale 2^30
 // (k_splat -> acc, converted to the fp32 IWE by the statistics pass), dL/dTheta and dL/dtheta as i64 at a per-window scale derived
@@ -132,7 +132,7 @@ __device__ __forceinline__ long long fix64_wide(double scaled) {
 //   per theta CELL (k_project's sums): all nev * R events, times <= 4 for the resampling weights (sum |A_H||A_W| of any method);
 //     < 2^61 (fix64_wide): at 10^7 events a 2^50 range left 1e-6 per rounding and 2e-5 relative error in the gradient.
 // Every event is rounded once at the fine pixel scale; a pixel's total is rounded once more when it enters a cell.
-// max |G| of a window = max over the per-tile maxima k_imgrad stored (R * ntiles words; plain stores there, because 4000
+// max |G| of a window = max over the per-strip maxima k_imgrad stored (R * nig words; plain stores there, because 4000
 // same-address atomicMax cost k_imgrad 18 us).  Called by every thread of a workgroup; result in all threads.  One __syncthreads.
 __device__ __forceinline__ double gmax_of(const unsigned* __restrict__ gmax_win, int n, unsigned* lds_scratch /* NWAVE words */) {
     unsigned m = 0u;
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         if (j + 2 < iters) step(C, A, B, j + 2);
     }
     if (!multi) __syncthreads();
-    // row-wise flush: a wave walks one window row -> contiguous u64 atomics on one image row.  The segment's exact integer sums
+    // flush (flat walk over the window: consecutive lanes, consecutive pixels of a row -> contiguous u64 atomics).  The segment's exact integer sums
     // (scale 2^fshift) are shifted to the accumulator's scale 2^ACC_SHIFT without rounding; integer adds commute, so the image
     // does not depend on the order in which the workgroups arrive.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(NT) void k_stats(Geom g, const float* __restrict__ 
     }
 }
 
-// k_iwe_finish: the u32 accumulator becomes the fp32 IWE stack, and is cleared for the next evaluation (consumer-clears).
+// k_iwe_finish: the u64 accumulator becomes the fp32 IWE stack, and is cleared for the next evaluation (consumer-clears).
 // Used on the paths whose statistics kernel is the tiled k_stats (forward-only evaluations); gradient evaluations do the same
 // inside k_stats_stream.  grid-stride over (B,R,H,W).
 constexpr double ACC_INV = 1.0 / 1073741824.0;     // 2^-ACC_SHIFT
