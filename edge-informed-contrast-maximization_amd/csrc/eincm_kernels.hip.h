@@ -921,7 +921,7 @@ __device__ __forceinline__ double mse_from_moments(const ImgScal& s, double sE, 
 // horizontal neighbours come from the adjacent lanes by DPP wave shifts (no LDS), its vertical neighbours from the
 // previous iterations.  Lanes 0,1,62,63 and rows -2,-1,+1,+2 of a strip are halo (5x5 support of the stacked stencils).
 // ------------------------------------------------------------------------------------------------
-constexpr int IG_ROWS = 16, IG_COLS = 60, IG_NT = 256;
+constexpr int IG_ROWS = 12, IG_COLS = 60, IG_NT = 256;      // rows: 16.5 / 15.7 / 16.0 us with 16 / 12 / 8 on the 8-window batch, 8.2 / 7.2 / 6.7 on one window (k_final pays for more strips)
 
 template <int CTRL> __device__ __forceinline__ float dpp_lane(float v) {       // zero where the source lane does not exist
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
