@@ -1208,11 +1208,14 @@ __device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, cons
     float gv[3][3];
     const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;
     if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
-        const float* p = lds + __mul24(ly, wn.ww) + lx;
+        // byte offsets with the row stride pre-scaled (a scalar): one v_mul_i32_i24 + one v_lshl_add_u32, then one add per further row
+        const int ww4 = wn.ww * 4;
+        const char* pb = reinterpret_cast<const char*>(lds) + (__mul24(ly, ww4) + (lx << 2));
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
+            const float* prow = reinterpret_cast<const float*>(pb + dy * ww4);
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) gv[dy][dx] = p[dy * wn.ww + dx];
+            for (int dx = 0; dx < 3; ++dx) gv[dy][dx] = prow[dx];
         }
     } else {
         const int sx = clamp_far(irx), sy = clamp_far(iry), lxs = sx - 1 - wn.ox, lys = sy - 1 - wn.oy;
