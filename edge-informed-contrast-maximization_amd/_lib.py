@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libeincm_hip.so')
+LIB_PATH = os.environ.get('EINCM_LIB') or os.path.join(_HERE, 'libeincm_hip.so')      # EINCM_LIB: a developer's variant build (tools/build_variant.sh)
 
 MAX_REFS = 16
 N_STAGES = 10
@@ -79,6 +79,7 @@ SIGNATURES = [
     ('eincm_resample_matrix', C.c_int, [C.c_int, C.c_int, C.c_int, _D]),
     ('eincm_get_timings', C.c_int, [_P, C.POINTER(Timings)]),
     ('eincm_set_timed_kernels', C.c_int, [_P, C.c_int, C.c_int]),
+    ('eincm_get_host_profile', C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     ('eincm_get_timings_total', C.c_int, [_P, C.POINTER(Timings), C.POINTER(C.c_int64), C.c_int]),
     ('eincm_set_windows_ex', C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int16),
                                        C.POINTER(C.c_int16), _D, _D, _D, C.c_uint32]),

@@ -9,6 +9,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -61,6 +62,7 @@ struct eincm_ctx {
     int32_t* d_order = nullptr;    // (max_items) d_items by decreasing length: the order the event kernels' workgroups take them in
     int32_t* d_order_s = nullptr;  // the same for d_items_s
     std::vector<int32_t> h_order, h_order_s, h_tilecount;   // host sides of the two (kept until the upload has completed)
+    std::vector<int32_t> h_win_item0;                       // host copy of d_win_item0
     Window* d_wins = nullptr;      // (max_items, maxR) destination windows of the gather segments under the current theta
     Window* d_wins_s = nullptr;    // (max_items, maxR) ... of the splat segments
     int n_items_s = 0; int seg_s = 0; int seg_s_used = 0;
@@ -91,6 +93,12 @@ struct eincm_ctx {
     double* d_dtmax = nullptr;     // (B) staging scratch: max |t - tau| per window
     unsigned* d_gmax = nullptr;    // (B,R,nig) per-strip max |dL/dIWE| as float bits (scale of the i64 gradient accumulators)
     unsigned* d_cntmax = nullptr;  // (B) staging scratch: most events on one source pixel
+    unsigned* d_amax = nullptr;    // (B,R,pstride) max |A| per k_imstat workgroup (float bits)
+    unsigned* d_gbound = nullptr;  // (B) bound of max |dL/dIWE| written by the composing gather (float bits): what gmax is when gmax_n == 1
+    float* d_Gimg = nullptr;       // (B,R,H,W) dL/dIWE materialised for eincm_get_image_grad after a composed evaluation (allocated on demand)
+    bool last_composed = false;    // the last gradient evaluation left A in d_G (the gather composed dL/dIWE on the fly)
+    EvalParams last_ep{};
+    Geom last_g{};                 // geometry of the last gradient evaluation (nparts, gmax_n)
     double* d_tvg = nullptr;       // (B,H,W,2)
     uint8_t* d_mask = nullptr;     // (B,H,W)
     double* d_tmm = nullptr;       // (B,ntiles,4)
@@ -118,6 +126,11 @@ struct eincm_ctx {
     double* h_grad = nullptr;
     OutScal* h_outs = nullptr;
     WinConst* h_wc = nullptr;
+    // host-assembled evaluations (2-DoF theta, no TV / divergence / full aux): the kernels write their partials straight into these
+    // and the host adds them in index order after the stream has drained (no k_final, no k_theta_const: two launches fewer per evaluation)
+    double* h_g11 = nullptr;       // (max_items + NXCD, R, 2) per-workgroup partials of dL/dtheta (k_gather)
+    double* h_g2 = nullptr;        // (B,R,nig) contrast energy per k_imgrad strip
+    double* h_img = nullptr;       // (B,R,IMGSCAL_N) reduced image scalars (k_imgrad)
 
     // timing.  EINCM_CF_TIMING_DOMINANT keeps a ring of event sets and reads them out later (eincm_get_timings*): asking HIP for
     // elapsed times after every evaluation cost the caller ~15 us per evaluation, which a throughput measurement should not pay.
@@ -143,7 +156,15 @@ struct eincm_ctx {
     bool G_valid = false;          // d_G holds dL/dIWE of the last evaluation (eincm_get_count_images borrows the buffer)
     int last_nparts = 0;           // how many StatParts per image the last evaluation wrote (k_stats vs k_stats_stream)
     // an evaluation split in two halves (eval_begin ... [caller may all-reduce the IWE stack] ... eval_end)
-    struct { bool active = false; bool launched = false; EvalParams ep{}; int h = 0, w = 0; bool identity = false, want_grad = false, full_aux = false, div_grad = false; } pend;
+    struct { bool active = false; bool launched = false; EvalParams ep{}; int h = 0, w = 0; bool identity = false, want_grad = false, full_aux = false, div_grad = false;
+             bool host_asm = false;                 // scalar assembly and the 2-DoF gradient sum on the host (see h_g11)
+             bool composed = false;                 // k_imstat + composing gather (host_assemble: the contrast energy rides in h_img)
+             bool use_arg = false; const double* theta_dev = nullptr; ThetaArg targ{};      // where the event kernels find a 2-DoF theta
+             } pend;
+    std::vector<uint8_t> theta_nan;    // (B) a NaN / Inf somewhere in window b's theta (host-assembled evaluations)
+    // host-side wall time of the phases of an evaluation (eincm_get_host_profile): a few clock reads per evaluation, always on
+    double hp_us[EINCM_N_HOST_PHASES] = {};
+    int64_t hp_n = 0;
     bool constants_pending = false;   // staged with EINCM_SW_DEFER_CONSTANTS and not finished yet
     bool acc_dirty = false;        // a forward half was launched and its consumers were not: accumulators must be memset before reuse
     bool Theta_valid = false;      // d_Theta holds the upsampled theta of the last evaluation (2-DoF evaluations skip the image)
@@ -151,6 +172,13 @@ struct eincm_ctx {
 };
 
 namespace {
+
+using hp_clock = std::chrono::steady_clock;
+struct HostPhase {                 // adds the lifetime of the object to ctx->hp_us[phase]
+    eincm_ctx* c; int phase; hp_clock::time_point t0;
+    HostPhase(eincm_ctx* c_, int p) : c(c_), phase(p), t0(hp_clock::now()) {}
+    ~HostPhase() { c->hp_us[phase] += std::chrono::duration<double, std::micro>(hp_clock::now() - t0).count(); }
+};
 
 int fail(eincm_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -235,13 +263,13 @@ void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_items_s); F(c->d_order); F(c->d_order_s); F(c->d_wins); F(c->d_wins_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
     F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_itembase_s); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_acc); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
-    F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax); F(c->d_cntmax);
+    F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax); F(c->d_cntmax); F(c->d_amax); F(c->d_gbound); F(c->d_Gimg);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
     F(c->d_divparts); F(c->d_g2parts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
     F(c->d_rowtap); F(c->d_coltap);
     for (DevBuf* b : {&c->e_u8, &c->e_g, &c->e_sq, &c->e_misc, &c->e_a, &c->e_b, &c->e_kern, &c->e_out}) { F(b->p); b->bytes = 0; }
     auto FH = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
-    FH(c->h_theta); FH(c->h_outs); c->h_grad = nullptr; FH(c->h_wc);
+    FH(c->h_theta); FH(c->h_outs); c->h_grad = nullptr; FH(c->h_wc); FH(c->h_g11); FH(c->h_g2); FH(c->h_img);
     if (c->have_events) {
         for (int k = 0; k < eincm_ctx::EV_RING; ++k)
             for (int i = 0; i <= EINCM_N_STAGES; ++i)
@@ -374,7 +402,7 @@ void launch_theta_image(eincm_ctx* c, int h, int w, bool identity, bool use_arg,
 
 // Launch the forward half: theta -> Theta -> u64 IWE accumulator.
 // need_theta_image: somebody will read d_Theta (TV term); 2-DoF evaluations otherwise skip the image altogether.
-int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_image, const double* theta_host) {
+int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_image, const double* theta_host, bool host_asm) {
     const Geom& g = c->g;
     const size_t nth = (size_t)h * w * 2;
     const bool use_arg = !identity && (size_t)g.B * nth <= (size_t)THETA_ARG_MAX;
@@ -406,9 +434,12 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
             c->last_theta11.assign(theta_host, theta_host + (size_t)g.B * 2);
             c->Theta_valid = false;
             if (need_theta_image) launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev, false);
-            launch_timed(c, EINCM_STAGE_THETA, k_theta_const, dim3((std::max(g.B * g.ntiles, nwin_threads) + NT - 1) / NT), dim3(NT), 0, g,
-                               use_arg ? 1 : 0, targ, theta_dev, c->d_tmm, c->d_edge_ts, c->n_items, c->d_items, c->d_wins,
-                               c->n_items_s, c->d_items_s, c->d_wins_s);
+            // the event kernels derive their windows from theta themselves; the velocity bounds (tmm) only feed k_final's NaN scan,
+            // which a host-assembled evaluation does on the host
+            if (!host_asm)
+                launch_timed(c, EINCM_STAGE_THETA, k_theta_const, dim3((std::max(g.B * g.ntiles, nwin_threads) + NT - 1) / NT), dim3(NT), 0, g,
+                                   use_arg ? 1 : 0, targ, theta_dev, c->d_tmm, c->d_edge_ts, c->n_items, c->d_items, c->d_wins,
+                                   c->n_items_s, c->d_items_s, c->d_wins_s);
         } else {
             launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev, true);
             if (nwin_threads > 0 && !c->itembase_valid)
@@ -425,7 +456,8 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
             const size_t lds_bytes = (size_t)(lds_multi ? 2 : 1) * g.wincap * sizeof(float)
                                    + (theta_mode == THETA_TILE ? TS * TS * sizeof(double2) : 0);
 #define SPLAT_ARGS(NTH) dim3(splat_grid(c)), dim3(NTH), lds_bytes, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
-                   c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wins_s, c->d_acc, c->d_order_s
+                   c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wins_s, c->d_acc, c->d_order_s, \
+                   use_arg ? 1 : 0, theta_dev, targ
             if (lds_multi)                      launch_timed(c, EINCM_STAGE_SPLAT, k_splat<0, 1, NT>, SPLAT_ARGS(NT));      // long segments (EINCM_SEG_SPLAT > EINCM_CHUNK)
             // 512 threads per workgroup in both compile-time modes: 93 vs 94 us on the 8-window batch, 18.8 vs 23.2 us on one window
             // (1024: 102 us; the gather is slower with 512: 93.5 vs 81.7 us)
@@ -435,6 +467,7 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
         }
     }
     HIPCHK(c, hipGetLastError());
+    c->pend.use_arg = use_arg; c->pend.theta_dev = theta_dev; c->pend.targ = targ;
     return EINCM_OK;
 }
 
@@ -469,6 +502,7 @@ int collect_timings(eincm_ctx* c) {
 
 // First half of an evaluation: theta -> Theta -> IWE stack (k_theta, k_splat).  theta_host: (B,h,w,2) doubles.
 int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_params* p, bool want_grad) {
+    HostPhase hp(c, EINCM_HP_BEGIN);
     const Geom& g = c->g;
     const bool identity = (h == g.H && w == g.W);
     const size_t img = (size_t)g.H * g.W;
@@ -535,10 +569,17 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         c->g.wincap = cap;
         c->g.winmaxw = std::max(40, (int)std::lround(std::sqrt((double)cap * 1.4)));
     }
-    int rc = launch_forward(c, h, w, identity, ep.want_tv != 0, theta_host);
+    // 2-DoF theta with nothing but the contrast and correlation terms (every level above 0 of the reference's pyramid at its first
+    // level, and the bench workload): the scalar assembly and the sum of the gather's per-workgroup partials run on the host
+    const bool host_asm = want_grad && !identity && h == 1 && w == 1 && !ep.want_div && !ep.want_tv && !full_aux && !getenv("EINCM_NO_HOST_ASM");
+    if (host_asm) {
+        c->theta_nan.assign((size_t)g.B, 0);
+        for (int b = 0; b < g.B; ++b) c->theta_nan[b] = !(std::isfinite(theta_host[2 * b]) && std::isfinite(theta_host[2 * b + 1]));
+    }
+    int rc = launch_forward(c, h, w, identity, ep.want_tv != 0, theta_host, host_asm);
     if (rc) return rc;
     c->pend.active = true; c->pend.ep = ep; c->pend.h = h; c->pend.w = w; c->pend.identity = identity;
-    c->pend.want_grad = want_grad; c->pend.full_aux = full_aux; c->pend.div_grad = div_grad;
+    c->pend.want_grad = want_grad; c->pend.full_aux = full_aux; c->pend.div_grad = div_grad; c->pend.host_asm = host_asm;
     return EINCM_OK;
 }
 
@@ -547,21 +588,36 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
 int eval_end_launch(eincm_ctx* c) {
     if (!c->pend.active) return fail(c, EINCM_ERR_STATE, "no evaluation in flight");
     if (c->pend.launched) return EINCM_OK;
+    HostPhase hp(c, EINCM_HP_LAUNCH);
     Geom g = c->g;
     const EvalParams ep = c->pend.ep;
     const int h = c->pend.h, w = c->pend.w;
     const bool identity = c->pend.identity, want_grad = c->pend.want_grad, full_aux = c->pend.full_aux, div_grad = c->pend.div_grad;
     const size_t nth = (size_t)h * w * 2;
     const bool timing = (c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)) != 0;
-    const bool g2_from_imgrad = want_grad && ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG;
+    const bool host_asm = c->pend.host_asm;
+    // The image pass of a gradient evaluation: k_imstat (statistics + the stats-independent part of dL/dIWE in one kernel), the gather
+    // composes dL/dIWE while staging its windows.  delta != 0 needs the divergence adjoint image in between: k_stats_stream / k_stats,
+    // k_divgrad, k_imgrad and a gather that reads the finished image, as do forward-only evaluations (no gather to compose in).
+    const bool compose = want_grad && !div_grad && !getenv("EINCM_NO_COMPOSE");
+    const bool g2_from_imgrad = !compose && want_grad && ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG;
     const bool zero_copy_out = !identity && (size_t)g.B * nth <= ZERO_COPY_MAX;
+    const bool stream_stats = host_asm || (g2_from_imgrad && g.ntiles >= NSPART);
+    const int n_imwg = (g.nig + IG_NT / 64 - 1) / (IG_NT / 64);
+    unsigned* gmax_buf = compose ? c->d_gbound : c->d_gmax;
+    g.gmax_n = compose ? 1 : g.R * g.nig;
+    c->pend.composed = compose;
     {
-        StageTimer t(c, EINCM_STAGE_STATS, g2_from_imgrad && g.ntiles >= NSPART);
-        // Gradient evaluations with the grad-mag contrast take the contrast energy from k_imgrad (which computes the Scharr
-        // images anyway), so the statistics are a pure streaming reduction with NSPART fat partials per image.
-        // Either way the statistics pass is the consumer of the u64 accumulator: it leaves the fp32 IWE stack in d_iwe and the
-        // accumulator zero again.
-        if (g2_from_imgrad && g.ntiles >= NSPART) {
+        StageTimer t(c, EINCM_STAGE_STATS, compose || stream_stats);
+        // Either way the statistics pass is the consumer of the u64 accumulator: it leaves the fp32 IWE stack in d_iwe (k_imstat
+        // leaves the clearing to the gather, the others clear the accumulator themselves).
+        if (compose) {
+            g.nparts = n_imwg;
+            launch_timed(c, EINCM_STAGE_STATS, k_imstat, dim3(n_imwg, g.R, g.B), dim3(IG_NT), 0, g, ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG ? 1 : 0,
+                         c->d_acc, c->d_edges, c->d_iwe, c->d_G, c->d_parts, c->d_amax);
+        } else if (stream_stats) {
+            // gradient evaluations with the grad-mag contrast take the contrast energy from k_imgrad (which computes the Scharr
+            // images anyway), so the statistics are a pure streaming reduction with NSPART fat partials per image
             g.nparts = NSPART;
             launch_timed(c, EINCM_STAGE_STATS, k_stats_stream, dim3(NSPART, g.R, g.B), dim3(NT), 0, g, c->d_acc, c->d_iwe, c->d_edges,
                          c->d_parts);
@@ -589,13 +645,14 @@ int eval_end_launch(eincm_ctx* c) {
     bool wide = false;
     for (int b = 0; b < g.B; ++b) wide = wide || (c->win_events[b] * (int64_t)g.R < 4096);
     if (want_grad) {
-        {
+        if (!compose) {
             StageTimer t(c, EINCM_STAGE_IMGRAD, !div_grad);
             if (div_grad)
                 hipLaunchKernelGGL(k_divgrad, dim3(g.ntiles, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_parts,
                                    c->d_gdiv, c->d_dgparts);
-            launch_timed(c, EINCM_STAGE_IMGRAD, k_imgrad, dim3((g.nig + IG_NT / 64 - 1) / (IG_NT / 64), g.R, g.B), dim3(IG_NT), 0, g, ep, c->d_iwe, c->d_edges,
-                               c->d_parts, c->d_wc, c->d_gdiv, c->d_dgparts, c->d_g2parts, c->d_G, c->d_gmax);
+            launch_timed(c, EINCM_STAGE_IMGRAD, k_imgrad, dim3(n_imwg, g.R, g.B), dim3(IG_NT), 0, g, ep, c->d_iwe, c->d_edges,
+                               c->d_parts, c->d_wc, c->d_gdiv, c->d_dgparts, host_asm ? c->h_g2 : c->d_g2parts, c->d_G, c->d_gmax,
+                               host_asm ? c->h_img : nullptr);
         }
         {
             StageTimer t(c, EINCM_STAGE_GATHER, true);
@@ -613,14 +670,19 @@ int eval_end_launch(eincm_ctx* c) {
 #define GATHER_ARGS(NTH) dim3(use_s ? splat_grid(c) : event_grid(c)), dim3(NTH), \
                     g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), \
                     g, n_g, items_g, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, wins_g, c->d_gTheta, \
-                    direct11 ? 1 : 0, c->d_g11, c->d_wc, c->d_gmax, direct11 ? THETA_CONST : THETA_TILE, order_g
+                    direct11 ? 1 : 0, host_asm ? c->h_g11 : c->d_g11, c->d_wc, gmax_buf, direct11 ? THETA_CONST : THETA_TILE, order_g, \
+                    c->pend.use_arg ? 1 : 0, c->pend.theta_dev, c->pend.targ, \
+                    ep, c->d_edges, c->d_iwe, c->d_parts, c->d_amax, c->d_acc, c->d_win_item0, (host_asm && compose) ? c->h_img : nullptr
                 if (direct11) {
-                    launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT>, GATHER_ARGS(NT));
+                    if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 1>, GATHER_ARGS(NT));
+                    else         launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 0>, GATHER_ARGS(NT));
                     c->g11_per_item = g.R;
                 } else if (wide) {
-                    launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 1, NT_TILE>, GATHER_ARGS(NT_TILE));
+                    if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 1, NT_TILE, 1>, GATHER_ARGS(NT_TILE));
+                    else         launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 1, NT_TILE, 0>, GATHER_ARGS(NT_TILE));
                 } else {
-                    launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 0, NT_TILE>, GATHER_ARGS(NT_TILE));
+                    if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 0, NT_TILE, 1>, GATHER_ARGS(NT_TILE));
+                    else         launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 0, NT_TILE, 0>, GATHER_ARGS(NT_TILE));
                 }
 #undef GATHER_ARGS
             }
@@ -632,24 +694,25 @@ int eval_end_launch(eincm_ctx* c) {
             StageTimer t(c, EINCM_STAGE_PROJECT, true);
             launch_timed(c, EINCM_STAGE_PROJECT, k_project, dim3(g.ntiles, g.B, nsrc), dim3(NT), 0, g, h, w,
                                (int)c->coarse_cap, direct11 ? 1 : 0, wide ? 1 : 0, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_gTheta, c->d_tvg,
-                               c->d_wc, c->d_gmax, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap);
+                               c->d_wc, gmax_buf, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap);
         }
     }
-    {
+    if (!host_asm) {
         StageTimer t(c, EINCM_STAGE_FINAL, !(want_grad && identity));
         // small results (everything but a dense gradient) are written by k_final straight into pinned host memory: no D2H copy command
         launch_timed(c, EINCM_STAGE_FINAL, k_final, dim3(g.B), dim3(FT), 0, g, ep, c->d_parts, c->d_divparts, c->d_tvparts,
                            c->d_tmm, c->d_wc, g2_from_imgrad ? c->d_g2parts : nullptr, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap,
-                           c->d_g11, c->d_win_item0, c->n_items, c->g11_per_item, c->d_gmax,
+                           c->d_g11, c->d_win_item0, c->n_items, c->g11_per_item, gmax_buf,
                            zero_copy_out ? c->h_outs : c->d_outs, zero_copy_out ? c->h_grad : c->d_grad, want_grad ? 1 : 0);
         if (want_grad && identity) {
             hipLaunchKernelGGL(k_final_dense, dim3(256, g.B), dim3(NT), 0, c->stream, g, ep.use_tv_grad, wide ? 1 : 0, c->d_gTheta,
-                               c->d_tvg, c->d_wc, c->d_gmax, c->d_outs, c->d_grad);
+                               c->d_tvg, c->d_wc, gmax_buf, c->d_outs, c->d_grad);
         }
     }
+    if (want_grad) { c->last_composed = compose; c->last_ep = ep; c->last_g = g; }
     HIPCHK(c, hipGetLastError());
     c->n_pieces = 0;
-    if (zero_copy_out) {
+    if (zero_copy_out || host_asm) {
         // nothing to copy
     } else if (want_grad && (size_t)g.B * nth >= ((size_t)1 << 17)) {
         // a dense gradient (4.9 MB at 480x640): in pieces, an event behind each, so that eval_end_collect hands piece k over
@@ -679,6 +742,58 @@ int eval_end_launch(eincm_ctx* c) {
     return EINCM_OK;
 }
 
+// Host-assembled evaluations (pend.host_asm): what k_final does for them, in fp64 on the host from the partials the kernels wrote
+// into pinned memory - the image scalars of k_imgrad (h_img), its per-strip contrast energies (h_g2) and the per-workgroup partials
+// of the 2-DoF gradient (h_g11) - every sum in index order, so the result is a function of the partials alone (bit-reproducible).
+// losses.py:176-203 without the TV / divergence terms (the caller routed those evaluations to k_final).
+void host_assemble(eincm_ctx* c) {
+    const Geom& g = c->g;
+    const EvalParams& ep = c->pend.ep;
+    const double HW = (double)g.H * (double)g.W, Rd = (double)g.R;
+    for (int b = 0; b < g.B; ++b) {
+        const WinConst& wc = c->h_wc[b];
+        OutScal& o = c->h_outs[b];
+        memset(&o, 0, sizeof o);
+        double sum_rel_con = 0.0, sum_rel_corr = 0.0;
+        for (int r = 0; r < g.R; ++r) {
+            const double* q = c->h_img + ((size_t)b * g.R + r) * IMGSCAL_N;
+            double zero_img[IMGSCAL_N] = {0.0, 0.0, EPSN, HW, HW, 0.0, 0.0, 0.0, 0.0};
+            if (c->pend.composed && c->win_events[b] == 0) q = zero_img;      // no segment, no gather workgroup: the IWE is identically zero
+            ImgScal s{};
+            s.m = q[0]; s.M = q[1]; s.D = q[2]; s.cm = q[3]; s.cM = q[4]; s.sI = q[5]; s.sII = q[6]; s.sEI = q[7];
+            double g2 = 0.0;
+            if (c->pend.composed) {
+                g2 = q[8];                           // k_imstat's per-workgroup energies, reduced with the other image scalars
+            } else {
+                const double* g2p = c->h_g2 + ((size_t)b * g.R + r) * g.nig;
+                for (int i = 0; i < g.nig; ++i) g2 += g2p[i];
+            }
+            const double mse = mse_from_moments(s, wc.sE[r], wc.sEE[r], HW);
+            const double mean = s.sI / HW;
+            const double var = s.sII / HW - mean * mean;
+            const double cgm = g2 / HW;
+            const double con = (ep.contrast_kind == 1) ? var : cgm;
+            const double c0 = (ep.contrast_kind == 1) ? wc.c0_var : wc.c0_gradmag;
+            o.corr[r] = -mse; o.contrast_gm[r] = cgm; o.var[r] = var; o.div[r] = NAN;
+            sum_rel_con += wc.mrw[r] * con / (c0 + EPSN);
+            sum_rel_corr += wc.mrw[r] * (-mse) / (wc.zc[r] + EPSN);
+        }
+        const double mrc = sum_rel_con / Rd, mrr = sum_rel_corr / Rd;
+        double val = ep.alpha * (-mrc) + ep.beta * (-mrr);
+        if (c->theta_nan[b]) val = NAN;             // a NaN anywhere in theta surfaces as a NaN loss, like in the reference
+        o.mean_rel_contrast = mrc; o.mean_rel_corr = mrr; o.mean_rel_div = NAN;
+        o.tv = (ep.cur_pyr_lvl <= 0) ? NAN : 0.0;
+        o.value = val; o.tv_scale = 0.0;
+        o.nonfinite = std::isfinite(val) ? 0.0 : 1.0;
+        const int lo = c->h_win_item0[b], hi = (b + 1 < g.B) ? c->h_win_item0[b + 1] : c->n_items;
+        const double* p = c->h_g11 + (size_t)lo * g.R * 2;
+        const size_t n = (size_t)(hi - lo) * g.R;
+        double sx = 0.0, sy = 0.0;
+        for (size_t k = 0; k < n; ++k) { sx += p[2 * k]; sy += p[2 * k + 1]; }
+        c->h_grad[(size_t)b * 2] = sx; c->h_grad[(size_t)b * 2 + 1] = sy;
+    }
+}
+
 // Second half, part 2: wait for the stream and hand the results over.
 int eval_end_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
     if (!c->pend.active || !c->pend.launched) return fail(c, EINCM_ERR_STATE, "no evaluation in flight");
@@ -705,9 +820,15 @@ int eval_end_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) 
             piece_bad = piece_bad || bad != 0;
         }
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        HostPhase hp(c, EINCM_HP_WAIT);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     c->pend.active = false; c->pend.launched = false;
+    ++c->hp_n;
     if (want_grad && !grad) return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
+    HostPhase hp(c, EINCM_HP_COLLECT);
+    if (c->pend.host_asm) host_assemble(c);
     int rc = collect_timings(c);
     if (rc) return rc;
     c->have_eval = true;
@@ -880,7 +1001,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
         TRY(dalloc(&c->d_itembase_s, B * ntiles));
         TRY(dalloc(&c->d_bin_misc, (size_t)8));
         TRY(dalloc(&c->d_edges_raw, B * R * img));
-        TRY(dalloc(&c->d_edge_moments, B * R * EDGE_PARTS * 2));
+        TRY(dalloc(&c->d_edge_moments, B * R * EDGE_PARTS * EDGE_MOM));
     }
     TRY(dalloc(&c->d_edges, B * R * img));
     TRY(dalloc(&c->d_edge_ts, B * R));
@@ -903,7 +1024,11 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_tvg, B * img * 2));
     TRY(dalloc(&c->d_mask, B * img));
     TRY(dalloc(&c->d_tmm, B * ntiles * 4));
-    TRY(dalloc(&c->d_parts, B * R * ntiles));
+    const size_t pstride = (size_t)std::max(std::max(ntiles, NSPART), (int)((nig + IG_NT / 64 - 1) / (IG_NT / 64)));
+    TRY(dalloc(&c->d_parts, B * R * pstride));
+    TRY(dalloc(&c->d_amax, B * R * pstride));
+    TRY(dalloc(&c->d_gbound, B));
+    TRY(hipMemset(c->d_gbound, 0, B * sizeof(unsigned)));
     TRY(dalloc(&c->d_divparts, B * R * ntiles));
     TRY(dalloc(&c->d_g2parts, B * R * nig));
     TRY(dalloc(&c->d_tvparts, B * ntiles * 3));
@@ -924,6 +1049,9 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_coltap, (size_t)W));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_theta), B * img * 2 * sizeof(double), hipHostMallocDefault));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_wc), B * sizeof(WinConst), hipHostMallocDefault));
+    TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_g11), (size_t)(c->max_items + NXCD) * R * 2 * sizeof(double), hipHostMallocDefault));
+    TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_g2), B * R * nig * sizeof(double), hipHostMallocDefault));
+    TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_img), B * R * IMGSCAL_N * sizeof(double), hipHostMallocDefault));
     c->have_events = true;
     for (int k = 0; k < eincm_ctx::GRAD_PIECES; ++k) TRY(hipEventCreateWithFlags(&c->ev_piece[k], hipEventDisableTiming));
     c->ring_size = (flags & EINCM_CF_TIMING_DOMINANT) && !(flags & EINCM_CF_TIMING) ? eincm_ctx::EV_RING : 1;
@@ -974,6 +1102,8 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     g.H = H; g.W = W; g.R = n_refs; g.B = n_windows;
     g.tilesX = (W + TS - 1) / TS; g.tilesY = (H + TS - 1) / TS; g.ntiles = g.tilesX * g.tilesY;
     g.igx = (W + IG_COLS - 1) / IG_COLS; g.nig = g.igx * ((H + IG_ROWS - 1) / IG_ROWS);
+    g.pstride = std::max(std::max(g.ntiles, NSPART), (g.nig + IG_NT / 64 - 1) / (IG_NT / 64));
+    g.gmax_n = g.R * g.nig;
     g.wincap = c->wincap; g.winmaxw = std::max(40, (int)std::lround(std::sqrt((double)c->wincap * 1.4)));
 
     // Segment lengths (events per workgroup and reference time), measured on MI355X with the longest-first order of block_to_work
@@ -1000,6 +1130,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             if (!std::isfinite(edge_ts[b * n_refs + r])) return fail(c, EINCM_ERR_ARG, "edge_ts[%d,%d] is not finite", b, r);
     }
     int n_items_total = 0, n_items_s_total = 0;
+    c->h_win_item0.assign((size_t)n_windows + 1, 0);
     std::vector<unsigned> cntmax_h((size_t)n_windows, 0u);
     std::vector<double> dtmax_h((size_t)n_windows, 0.0);
     std::vector<int32_t> item0_h;                  // host path only
@@ -1048,7 +1179,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         hipLaunchKernelGGL(k_bin_tilescan, dim3(1), dim3(1024), 0, c->stream, M, seg, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_bin_misc);
         HIPCHK(c, hipGetLastError());
         int32_t misc[4];
-        std::vector<double> mom((size_t)n_windows * n_refs * EDGE_PARTS * 2);
+        std::vector<double> mom((size_t)n_windows * n_refs * EDGE_PARTS * EDGE_MOM);
         HIPCHK(c, hipMemcpyAsync(misc, c->d_bin_misc, sizeof misc, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(mom.data(), c->d_edge_moments, mom.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         c->h_tilecount.resize((size_t)M);
@@ -1071,9 +1202,12 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         if (n_items_total > c->max_items) return fail(c, EINCM_ERR_ARG, "internal: %d segments exceed capacity", n_items_total);
         for (int b = 0; b < n_windows; ++b)
             for (int r = 0; r < n_refs; ++r) {          // the blocks' partials, added in index order
-                double sE = 0.0, sEE = 0.0;
-                for (int k = 0; k < EDGE_PARTS; ++k) { const double* m = &mom[(((size_t)b * n_refs + r) * EDGE_PARTS + k) * 2]; sE += m[0]; sEE += m[1]; }
-                c->h_wc[b].sE[r] = sE; c->h_wc[b].sEE[r] = sEE;
+                double sE = 0.0, sEE = 0.0, eabs = 0.0;
+                for (int k = 0; k < EDGE_PARTS; ++k) {
+                    const double* m = &mom[(((size_t)b * n_refs + r) * EDGE_PARTS + k) * EDGE_MOM];
+                    sE += m[0]; sEE += m[1]; eabs = std::max(eabs, m[2]);
+                }
+                c->h_wc[b].sE[r] = sE; c->h_wc[b].sEE[r] = sEE; c->h_wc[b].eabs[r] = eabs;
             }
         if (nblk > 0) {
             hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(BIN_NT), g.ntiles * sizeof(uint32_t), c->stream, g, c->d_binblocks, c->d_raw_x, c->d_raw_y,
@@ -1088,6 +1222,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             hipLaunchKernelGGL(k_win_consts, dim3(n_windows), dim3(NT), 0, c->stream, g, n_items_total, c->d_items, c->d_itembase, c->d_edge_ts,
                                c->d_win_item0, c->d_dtmax);
             HIPCHK(c, hipMemcpyAsync(dtmax_h.data(), c->d_dtmax, (size_t)n_windows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_win_item0.data(), c->d_win_item0, (size_t)n_windows * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
             // second segmentation of the same binned events for k_splat
             hipLaunchKernelGGL(k_bin_tilescan, dim3(1), dim3(1024), 0, c->stream, M, seg_s, c->d_tilecount, c->d_tilebase, c->d_itembase_s, c->d_bin_misc);
             HIPCHK(c, hipMemcpyAsync(misc, c->d_bin_misc, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1174,9 +1309,9 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         for (int r = 0; r < n_refs; ++r) {
             const double* e = edges_w[b] + (size_t)r * img;
             float* o = ef.data() + ((size_t)b * n_refs + r) * img;
-            double s = 0.0, ss = 0.0;
-            for (size_t i = 0; i < img; ++i) { const float f = (float)e[i]; o[i] = f; s += (double)f; ss += (double)f * (double)f; }
-            wc.sE[r] = s; wc.sEE[r] = ss;
+            double s = 0.0, ss = 0.0, mx = 0.0;
+            for (size_t i = 0; i < img; ++i) { const float f = (float)e[i]; o[i] = f; s += (double)f; ss += (double)f * (double)f; mx = std::max(mx, std::fabs((double)f)); }
+            wc.sE[r] = s; wc.sEE[r] = ss; wc.eabs[r] = mx;
         }
     }
     if (N > 0) {
@@ -1200,6 +1335,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             HIPCHK(c, hipMemcpyAsync(c->d_order_s, c->h_order_s.data(), c->h_order_s.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->d_win_item0, item0_h.data(), item0_h.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    std::copy(item0_h.begin(), item0_h.end(), c->h_win_item0.begin());
     HIPCHK(c, hipMemcpyAsync(c->d_edges, ef.data(), ef.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));     // host vectors go out of scope
     }
@@ -1462,6 +1598,17 @@ int eincm_get_zero_iwe(eincm_ctx* c, float* z) {
 int eincm_get_image_grad(eincm_ctx* c, float* G) {
     if (c && !c->have_eval) return fail(c, EINCM_ERR_STATE, "no evaluation yet");
     if (c && !c->G_valid) return fail(c, EINCM_ERR_STATE, "no dL/dIWE image: the last evaluation had no gradient, or eincm_get_count_images reused the buffer");
+    if (c && c->last_composed) {
+        // the gather composed dL/dIWE while staging its windows; materialise the same image (same function, same scalars) on demand
+        HIPCHK(c, hipSetDevice(c->device));
+        const Geom& g = c->last_g;
+        const size_t n = (size_t)c->maxB * c->maxR * c->H * c->W;
+        if (!c->d_Gimg) HIPCHK(c, dalloc(&c->d_Gimg, n));
+        hipLaunchKernelGGL(k_compose, dim3(64, g.R, g.B), dim3(NT), 0, c->stream, g, c->last_ep, c->d_G, c->d_edges, c->d_iwe, c->d_parts,
+                           c->d_wc, c->d_Gimg);
+        HIPCHK(c, hipGetLastError());
+        return copy_out(c, G, c->d_Gimg, (size_t)g.B * g.R * g.H * g.W * sizeof(float));
+    }
     return copy_out(c, G, c ? c->d_G : nullptr, c ? (size_t)c->g.B * c->g.R * c->g.H * c->g.W * sizeof(float) : 0);
 }
 // 2-DoF evaluations skip the Theta image; build it when somebody asks for it
@@ -1643,6 +1790,14 @@ int eincm_get_timings_total(eincm_ctx* c, eincm_timings* t, int64_t* n_evals, in
     if (rc) return rc;
     *t = c->sum_t; *n_evals = c->sum_n;
     if (reset) { c->sum_t = eincm_timings{}; c->sum_n = 0; }
+    return EINCM_OK;
+}
+
+int eincm_get_host_profile(eincm_ctx* c, double* us, int64_t* n_evals, int reset) {
+    if (!c || !us || !n_evals) return EINCM_ERR_ARG;
+    for (int i = 0; i < EINCM_N_HOST_PHASES; ++i) us[i] = c->hp_us[i];
+    *n_evals = c->hp_n;
+    if (reset) { for (double& v : c->hp_us) v = 0.0; c->hp_n = 0; }
     return EINCM_OK;
 }
 

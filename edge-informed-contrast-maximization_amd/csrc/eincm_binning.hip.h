@@ -208,25 +208,32 @@ __global__ __launch_bounds__(NT) void k_seg_minmax(int n_items, Item* __restrict
     }
 }
 
-// edges (B,R,H,W) double -> float, and the fp64 moments of the STORED values: sum E, sum E^2 per (b, r), as one partial pair
+// edges (B,R,H,W) double -> float, and the fp64 moments of the STORED values: sum E, sum E^2 (and max |E|) per (b, r), as one partial triple
 // per block (the host adds the EDGE_PARTS pairs in index order: no atomics, bit-reproducible).  grid (EDGE_PARTS, R, B).
 constexpr int EDGE_PARTS = 32;
+constexpr int EDGE_MOM = 3;               // per part: sum E, sum E^2, max |E|
 __global__ __launch_bounds__(NT) void k_edges(Geom g, const double* __restrict__ src, float* __restrict__ dst, double* __restrict__ moments)
 {
     __shared__ double scratch[NWAVE];
     const int r = blockIdx.y, b = blockIdx.z;
     const size_t n = (size_t)g.H * g.W, base = ((size_t)b * g.R + r) * n;
-    double s = 0.0, ss = 0.0;
+    double s = 0.0, ss = 0.0, mx = 0.0;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
         const float f = (float)src[base + i];
         dst[base + i] = f;
         s += (double)f; ss += (double)f * (double)f;
+        mx = fmax(mx, fabs((double)f));             // fmax drops a NaN: a NaN edge map surfaces in the sums
     }
     s = block_sum(s, scratch);
     ss = block_sum(ss, scratch);
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = mx;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        double* o = moments + (((size_t)b * g.R + r) * EDGE_PARTS + blockIdx.x) * 2;
-        o[0] = s; o[1] = ss;
+        for (int i = 1; i < NWAVE; ++i) mx = fmax(mx, scratch[i]);
+        double* o = moments + (((size_t)b * g.R + r) * EDGE_PARTS + blockIdx.x) * EDGE_MOM;
+        o[0] = s; o[1] = ss; o[2] = mx;
     }
 }
 

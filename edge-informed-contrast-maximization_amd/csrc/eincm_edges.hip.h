@@ -134,7 +134,7 @@ __global__ __launch_bounds__(NT) void k_tiled(Geom g, int th, int tw, int ntx, c
     const int y0 = (tile / ntx) * th, x0 = (tile % ntx) * tw;
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
     const float* __restrict__ E = edges + ((size_t)b * g.R + r) * g.H * g.W;
-    const ImgScal sc = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
+    const ImgScal sc = reduce_parts(parts + ((size_t)b * g.R + r) * g.pstride, g.nparts);
     const auto at = [&](int ly, int lx) -> double {
         return (ly >= 0 && ly < th && lx >= 0 && lx < tw) ? (double)I[(size_t)(y0 + ly) * g.W + x0 + lx] : 0.0;
     };
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NT) void k_pair_objectives(Geom g, const float* __r
     const int r = blockIdx.y, b = blockIdx.z;
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
     const float* __restrict__ E = edges + ((size_t)b * g.R + r) * g.H * g.W;
-    const ImgScal sc = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
+    const ImgScal sc = reduce_parts(parts + ((size_t)b * g.R + r) * g.pstride, g.nparts);
     const auto nrm = [&](int y, int x) -> double { return ((double)I[(size_t)y * g.W + x] - sc.m) / sc.D; };
     const auto joint = [&](int y, int x) -> double {
         return (y >= 0 && y < g.H && x >= 0 && x < g.W) ? (double)E[(size_t)y * g.W + x] + nrm(y, x) : 0.0;

@@ -64,6 +64,8 @@ struct Geom {
     int tilesX, tilesY, ntiles;
     int wincap, winmaxw;      // LDS destination-window capacity (pixels) and maximum width of the event kernels
     int nparts;               // StatParts per image written by the statistics kernel of this evaluation (ntiles or NSPART)
+    int pstride;              // StatPart slots per image: max(ntiles, NSPART, k_imstat workgroups per image)
+    int gmax_n;               // words of `gmax` per window: R * nig per-strip maxima of k_imgrad, or 1 bound written by the composing gather
     int igx, nig;             // k_imgrad strips per image row / per image (IG_COLS x IG_ROWS pixels each): slots of g2parts and gmax
 };
 
@@ -80,11 +82,13 @@ struct StatPart {                 // per (window, ref, tile) partial of the imag
 struct ImgScal {                  // per (window, ref) reduced scalars
     double m, M, D, cm, cM, sI, sII, sEI, sG2;
 };
+constexpr int IMGSCAL_N = 9;      // doubles per image handed to the host: m, M, D, cm, cM, sI, sII, sEI, sG2
 
 struct WinConst {                 // theta-independent constants of a window (losses.py:54-55,66,71,80,84)
     double c0_gradmag, c0_var, d0;
     double zc[16];                // zero_corrs[r] = -MSE(E_r, n0)
     double sE[16], sEE[16];       // sum E_r, sum E_r^2
+    double eabs[16];              // max |E_r| (bounds dL/dIWE: gbound_from)
     double mrw[16];               // multi-reference weights (losses.py:39-46)
     double dtmax;                 // max |t_e - tau_r| over the window's events and reference times (bounds a gradient term)
     double nev;                   // events staged in this window of this context
@@ -255,6 +259,10 @@ __device__ __forceinline__ Window item_window(const Geom& g, const Item& it, con
 // (event_utils.py:32-33): w = x - v*dt (fp64, same operations as the reference so the half-to-even rounding
 // decisions agree), r = rint(w), f = w - r in [-0.5, 0.5] (exact in fp64), returned as (int r, float f).
 __device__ __forceinline__ void warp_axis(int x, double v, double dt, int& ir, float& f) {
+    // no FMA contraction: the reference rounds the product theta * dt before the subtraction (event_warpers.py:34-35; XLA's CPU
+    // backend does not contract without fast-math, numpy cannot).  fma(-v, dt, x) differs from that in the last bit of w, which
+    // decides rint() for events within 1e-16 relative of a half-integer (tests/test_gpu_parity.py::test_warp_rounds_the_product_first).
+#pragma clang fp contract(off)
     const double w = (double)x - v * dt;
     const double r = rint(w);
     f = (float)(w - r);                              // garbage when the event is off-sensor, but then every tap is dropped
@@ -576,9 +584,10 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         const double* __restrict__ Theta,      // (B,H,W,2)
         const double* __restrict__ tmm,        // (B,ntiles,4)
         const double* __restrict__ edge_ts,    // (B,R)
-        const Window* __restrict__ wins,       // (n_items, R) destination windows of this evaluation (k_theta_const / k_windows)
+        const Window* __restrict__ wins,       // (n_items, R) destination windows of this evaluation (k_theta / k_windows); unused for 2-DoF theta
         unsigned long long* __restrict__ acc,  // (B,R,H,W) u64 fixed point at 2^ACC_SHIFT, zero on entry (cleared by its consumer)
-        const int32_t* __restrict__ order)     // (n_items) segments by decreasing length (block_to_work)
+        const int32_t* __restrict__ order,     // (n_items) segments by decreasing length (block_to_work)
+        int use_arg, const double* __restrict__ theta_c, ThetaArg targ)   // 2-DoF theta (B,2): in the kernel arguments, or behind theta_c
 {
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsu[];
@@ -590,17 +599,21 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
     const double tau = edge_ts[it.win * g.R + r];
     const int tx0 = (it.tile % g.tilesX) * TS, ty0 = (it.tile / g.tilesX) * TS;
     double2 vconst = make_double2(0.0, 0.0);
+    Window wn;
     if (theta_mode == THETA_CONST) {
-        const double* mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
-        vconst = make_double2(mm[0], mm[2]);
+        // 2-DoF theta: Theta is one constant per window, so the workgroup derives its destination window itself (no k_theta_const
+        // launch in front of the splat, no table): ~150 uniform instructions against a dependent kernel boundary per evaluation
+        vconst = use_arg ? make_double2(targ.v[2 * it.win], targ.v[2 * it.win + 1]) : make_double2(theta_c[2 * it.win], theta_c[2 * it.win + 1]);
+        const double mm4[4] = {vconst.x, vconst.x, vconst.y, vconst.y};
+        wn = item_window(g, it, mm4, tau);
     } else {
         const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
         for (int p = threadIdx.x; p < TS * TS; p += NTH) {
             const int y = ty0 + p / TS, x = tx0 + p % TS;
             thtile[p] = (y < g.H && x < g.W) ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : make_double2(0.0, 0.0);
         }
+        wn = wins[(size_t)item * g.R + r];
     }
-    const Window wn = wins[(size_t)item * g.R + r];
     const int nwin = wn.ww * wn.wh;
     const bool multi = MULTI != 0 && it.count > chunk;       // MULTI == 0: the commit logic in the loop folds away
     {   // clear the window(s), 16 B per lane
@@ -685,12 +698,17 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
     load_ev(A, tid);
     load_ev(B, tid + NTH);
     C.xy = 0u; C.t = 0.0;
+#ifndef EINCM_ABL_S_NOEVENTS           // EINCM_ABL_*: timing-only ablation builds (tools/build_variant.sh); results are wrong by design
     for (int j = 0; j < iters; j += 3) {
         step(A, B, C, j);
         if (j + 1 < iters) step(B, C, A, j + 1);
         if (j + 2 < iters) step(C, A, B, j + 2);
     }
+#endif
     if (!multi) __syncthreads();
+#ifdef EINCM_ABL_S_NOFLUSH
+    return;
+#endif
     // flush (flat walk over the window: consecutive lanes, consecutive pixels of a row -> contiguous u64 atomics).  The segment's exact integer sums
     // (scale 2^fshift) are shifted to the accumulator's scale 2^ACC_SHIFT without rounding; integer adds commute, so the image
     // does not depend on the order in which the workgroups arrive.
@@ -801,7 +819,7 @@ __global__ __launch_bounds__(NT) void k_stats(Geom g, const float* __restrict__ 
             if (red[i][1] > o.mx) { o.mx = red[i][1]; o.cmx = red[i][3]; } else if (red[i][1] == o.mx) o.cmx += red[i][3];
             o.sI += red[i][4]; o.sII += red[i][5]; o.sEI += red[i][6]; o.sG2 += red[i][7];
         }
-        parts[((size_t)b * g.R + r) * g.ntiles + tile] = o;
+        parts[((size_t)b * g.R + r) * g.pstride + tile] = o;
     }
 }
 
@@ -881,7 +899,7 @@ __global__ __launch_bounds__(NT) void k_stats_stream(Geom g, unsigned long long*
             if (red[i][1] > o.mx) { o.mx = red[i][1]; o.cmx = red[i][3]; } else if (red[i][1] == o.mx) o.cmx += red[i][3];
             o.sI += red[i][4]; o.sII += red[i][5]; o.sEI += red[i][6];
         }
-        parts[((size_t)b * g.R + r) * g.ntiles + part] = o;      // slots [0, NSPART) of the image's ntiles-sized row (ntiles >= NSPART checked on the host)
+        parts[((size_t)b * g.R + r) * g.pstride + part] = o;     // slots [0, NSPART) of the image's row of pstride = max(ntiles, NSPART) slots
     }
 }
 
@@ -907,7 +925,7 @@ __device__ __forceinline__ ImgScal reduce_parts(const StatPart* __restrict__ par
 }
 
 // mean((E - n)^2) with n = (I - m)/D from the moments (correlation_objectives.py:25-26 on img_utils.py:24-25)
-__device__ __forceinline__ double mse_from_moments(const ImgScal& s, double sE, double sEE, double HW) {
+__host__ __device__ __forceinline__ double mse_from_moments(const ImgScal& s, double sE, double sEE, double HW) {
     const double a = s.m / s.D;
     return (sEE + HW * a * a + s.sII / (s.D * s.D) + 2.0 * a * sE - 2.0 * s.sEI / s.D - 2.0 * a * s.sI / s.D) / HW;
 }
@@ -935,8 +953,10 @@ __global__ __launch_bounds__(IG_NT) void k_imgrad(Geom g, EvalParams ep,
         const float* __restrict__ gdiv, const double* __restrict__ dgparts,    // delta != 0 only (else unused)
         double* __restrict__ g2parts,          // (B,R,nig): this strip's sum of gx^2+gy^2 (contrast energy), a by-product
         float* __restrict__ G,
-        unsigned* __restrict__ gmax)           // (B,R,nig): this strip's max |G| as float bits: fixes the fixed-point scale of the
+        unsigned* __restrict__ gmax,           // (B,R,nig): this strip's max |G| as float bits: fixes the fixed-point scale of the
                                                // gradient accumulators (gmax_of, grad_shift)
+        double* __restrict__ imgscal_out)      // (B,R,IMGSCAL_N) or nullptr: the reduced image scalars, written once per image (in pinned host
+                                               // memory on the path whose scalar assembly runs on the host: host_assemble)
 {
     __shared__ double sc[10];
     const bool use_div = (ep.delta != 0.0);
@@ -960,12 +980,16 @@ __global__ __launch_bounds__(IG_NT) void k_imgrad(Geom g, EvalParams ep,
     for (int k = 0; k < IG_ROWS; ++k) erow[k] = E[(size_t)min(cy0 + k, g.H - 1) * g.W + xc];
 
     if (threadIdx.x < 64) {
-        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
+        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.pstride, g.nparts);
         double dAn = 0.0, dA = 0.0;
         if (use_div) {
             const double* dp = dgparts + ((size_t)b * g.R + r) * g.ntiles * 2;
             for (int i = threadIdx.x; i < g.ntiles; i += 64) { dAn += dp[2 * i]; dA += dp[2 * i + 1]; }
             dAn = __shfl(wave_sum(dAn), 0, 64); dA = __shfl(wave_sum(dA), 0, 64);
+        }
+        if (threadIdx.x == 0 && blockIdx.x == 0 && imgscal_out) {
+            double* o = imgscal_out + ((size_t)b * g.R + r) * IMGSCAL_N;
+            o[0] = s.m; o[1] = s.M; o[2] = s.D; o[3] = s.cm; o[4] = s.cM; o[5] = s.sI; o[6] = s.sII; o[7] = s.sEI;
         }
         if (threadIdx.x == 0) {
             const double c0 = (ep.contrast_kind == 1) ? c.c0_var : c.c0_gradmag;
@@ -1048,6 +1072,155 @@ __global__ __launch_bounds__(IG_NT) void k_imgrad(Geom g, EvalParams ep,
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_imstat: the image pass of a gradient evaluation in ONE kernel (round 3): consumer of the u64 accumulator (exact sum -> fp32 IWE,
+// one rounding), image statistics (min / max with tie counts, sum I, sum I^2, sum E I) and the stats-INDEPENDENT part of dL/dIWE:
+//   A = adj_Sx(gx) + adj_Sy(gy) = -(conv(gx, Sx) + conv(gy, Sy)),  (gx, gy) = Scharr(I)      [reverse of contrast_objectives.py:22-25]
+// with the contrast energy sum(gx^2 + gy^2) and max |A| as by-products.  What depends on the statistics,
+//   G = k_c A + k_n (E - n) + k_m [I == m] + k_M [I == M],   n = (I - m) / D                  [reverse of img_utils.py:24-25, losses.py:62-67]
+// is linear in per-image scalars, so the gather composes G while it stages its window (compose_G) and no kernel has to wait for the
+// statistics in between: splat -> imstat -> gather instead of splat -> stats -> imgrad -> gather (a dependent kernel costs 6-8 us
+// here whatever its work: profiles/r03/latency_chain.md).  Same register sliding window as k_imgrad (a lane owns a column, DPP
+// neighbours, no LDS).  The accumulator is NOT cleared here (a neighbour strip still reads its halo from it): the gather does that.
+// grid (ceil(nig / 4), R, B); one StatPart per workgroup (its <= 4 strips combined), sG2 = contrast energy.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(IG_NT) void k_imstat(Geom g, int gradmag,
+        const unsigned long long* __restrict__ acc, const float* __restrict__ edges,
+        float* __restrict__ iwe, float* __restrict__ A,
+        StatPart* __restrict__ parts,          // (B,R,pstride): slot blockIdx.x
+        unsigned* __restrict__ amax)           // (B,R,pstride): max |A| of the workgroup's strips as float bits
+{
+    __shared__ double red[IG_NT / 64][8];
+    __shared__ unsigned redm[IG_NT / 64];
+    const int r = blockIdx.y, b = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * (IG_NT / 64) + wv);   // wave-uniform: row tests stay scalar
+    const size_t img = ((size_t)b * g.R + r) * g.H * g.W;
+    const unsigned long long* __restrict__ Ac = acc + img;
+    const float* __restrict__ E = edges + img;
+    float* __restrict__ Io = iwe + img;
+    float* __restrict__ Ao = A + img;
+    const bool live = strip < g.nig;                          // wave-uniform; dead waves run the loop on clamped addresses and contribute nothing
+    const int sidx = live ? strip : 0;
+    const int cx0 = (sidx % g.igx) * IG_COLS, cy0 = (sidx / g.igx) * IG_ROWS;
+    const int x = cx0 - 2 + lane;
+    const int xc = min(max(x, 0), g.W - 1);
+    unsigned long long arow[IG_ROWS + 4];
+    float erow[IG_ROWS];
+#pragma unroll
+    for (int k = 0; k < IG_ROWS + 4; ++k) arow[k] = Ac[(size_t)min(max(cy0 - 2 + k, 0), g.H - 1) * g.W + xc];
+#pragma unroll
+    for (int k = 0; k < IG_ROWS; ++k) erow[k] = E[(size_t)min(cy0 + k, g.H - 1) * g.W + xc];
+    const bool col_in = (x >= 0 && x < g.W);
+    const bool own = live && col_in && lane >= 2 && lane < 2 + IG_COLS;
+    const int yend = min(cy0 + IG_ROWS, g.H);                // own rows [cy0, yend)
+
+    float tA = 0.f, tB = 0.f, dA = 0.f, dB = 0.f, gyA = 0.f, gyB = 0.f, qA = 0.f, qB = 0.f;
+    float g2f = 0.f;
+    unsigned am = 0u;
+    double mn = INFINITY, mx = -INFINITY, cmn = 0.0, cmx = 0.0, sI = 0.0, sII = 0.0, sEI = 0.0;
+#pragma unroll
+    for (int k = 0; k < IG_ROWS + 4; ++k) {
+        const int i = cy0 - 2 + k;
+        const float tv = (float)((double)arow[k] * ACC_INV);                  // exact u64 sum -> fp32 pixel (one rounding), as k_stats_stream
+        const float tC = (i >= 0 && i < g.H && col_in) ? tv : 0.0f;           // zero padding (Scharr 'same')
+        float ax = 0.f, ay = 0.f, dC = 0.f, gy = 0.f, qC = 0.f;
+        if (gradmag) {                                       // uniform: the DPP moves below always run with every lane enabled
+            dC = lane_p1(tC) - lane_m1(tC);
+            float gx = 3.0f * dC + 10.0f * dB + 3.0f * dA;
+            const float e = tC - tA;
+            gy = 3.0f * lane_p1(e) + 10.0f * e + 3.0f * lane_m1(e);
+            const bool in1 = (i - 1 >= 0 && i - 1 < g.H) && col_in;
+            gx = in1 ? gx : 0.0f; gy = in1 ? gy : 0.0f;
+            const bool own1 = own && (i - 1 >= cy0 && i - 1 < yend);
+            g2f += own1 ? (gx * gx + gy * gy) : 0.0f;
+            qC = lane_p1(gx) - lane_m1(gx);
+            ax = 3.0f * qC + 10.0f * qB + 3.0f * qA;
+            const float eg = gy - gyA;
+            ay = 3.0f * lane_p1(eg) + 10.0f * eg + 3.0f * lane_m1(eg);
+        }
+        const int o = i - 2;
+        if (o >= cy0 && o < yend && own) {
+            const float af = -(ax + ay);
+            Io[(size_t)o * g.W + x] = tA;
+            if (gradmag) { Ao[(size_t)o * g.W + x] = af; am = max(am, __float_as_uint(af) & 0x7fffffffu); }
+            const double v = (double)tA, e = (double)erow[k >= 4 ? k - 4 : 0];
+            cmn = (v < mn) ? 1.0 : cmn + (v == mn ? 1.0 : 0.0);
+            cmx = (v > mx) ? 1.0 : cmx + (v == mx ? 1.0 : 0.0);
+            mn = fmin(mn, v); mx = fmax(mx, v);
+            sI += v; sII += v * v; sEI += e * v;
+        }
+        tA = tB; tB = tC; dA = dB; dB = dC; gyA = gyB; gyB = gy; qA = qB; qB = qC;
+    }
+    // wave, then workgroup: (min, #ties) and (max, #ties) combine associatively; sums in the fixed order of the trees
+    const double wmn = wave_min(mn), wmx = wave_max(mx);
+    const double bmn = __shfl(wmn, 0, 64), bmx = __shfl(wmx, 0, 64);
+    cmn = wave_sum(mn == bmn ? cmn : 0.0);
+    cmx = wave_sum(mx == bmx ? cmx : 0.0);
+    sI = wave_sum(sI); sII = wave_sum(sII); sEI = wave_sum(sEI);
+    const double g2 = wave_sum((double)g2f);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = max(am, (unsigned)__shfl_down((int)am, o, 64));
+    if (lane == 0) {
+        red[wv][0] = bmn; red[wv][1] = bmx; red[wv][2] = cmn; red[wv][3] = cmx; red[wv][4] = sI; red[wv][5] = sII; red[wv][6] = sEI; red[wv][7] = g2;
+        redm[wv] = am;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        StatPart o;
+        o.mn = red[0][0]; o.mx = red[0][1]; o.cmn = red[0][2]; o.cmx = red[0][3]; o.sI = red[0][4]; o.sII = red[0][5]; o.sEI = red[0][6]; o.sG2 = red[0][7];
+        unsigned m = redm[0];
+        for (int i = 1; i < IG_NT / 64; ++i) {
+            if (red[i][0] < o.mn) { o.mn = red[i][0]; o.cmn = red[i][2]; } else if (red[i][0] == o.mn) o.cmn += red[i][2];
+            if (red[i][1] > o.mx) { o.mx = red[i][1]; o.cmx = red[i][3]; } else if (red[i][1] == o.mx) o.cmx += red[i][3];
+            o.sI += red[i][4]; o.sII += red[i][5]; o.sEI += red[i][6]; o.sG2 += red[i][7];
+            m = max(m, redm[i]);
+        }
+        parts[((size_t)b * g.R + r) * g.pstride + blockIdx.x] = o;
+        amax[((size_t)b * g.R + r) * g.pstride + blockIdx.x] = m;
+    }
+}
+
+// The per-image scalars G is composed from (see k_imstat), in the precision the composition runs in (fp32 like the image itself;
+// the fp64 originals are the formulas of k_imgrad).  gradmag = 0: the variance contrast, dc = I - mean I.
+struct GCoef { float m, M, invD, k_c, k_n, k_m, k_M, meanI; };
+__device__ __forceinline__ GCoef gcoef_from(const ImgScal& s, const WinConst& c, const EvalParams& ep, int r, int R, double HW) {
+    const double c0 = (ep.contrast_kind == 1) ? c.c0_var : c.c0_gradmag;
+    const double a_r = -ep.alpha * c.mrw[r] / ((double)R * (c0 + EPSN));
+    const double b_r = -ep.beta * c.mrw[r] / ((double)R * (c.zc[r] + EPSN));
+    const double a = s.m / s.D;
+    const double S_n = s.sI / s.D - HW * a;
+    const double S_En = s.sEI / s.D - a * c.sE[r];
+    const double S_nn = s.sII / (s.D * s.D) - 2.0 * a * s.sI / s.D + HW * a * a;
+    const double k = b_r * 2.0 / HW;
+    const double sGn_n = k * (S_En - S_nn);                  // sum Gn*n
+    const double sGn = k * (c.sE[r] - S_n);                  // sum Gn
+    GCoef q;
+    q.m = (float)s.m; q.M = (float)s.M;                      // exact: extrema of fp32 pixels
+    q.invD = (float)(1.0 / s.D);
+    q.k_c = (float)(a_r * 2.0 / HW);
+    q.k_n = (float)(k / s.D);
+    q.k_m = (float)(((sGn_n - sGn) / s.D) / s.cm);           // dm / #argmin
+    q.k_M = (float)((-sGn_n / s.D) / s.cM);                  // dM / #argmax
+    q.meanI = (float)(s.sI / HW);
+    return q;
+}
+// An upper bound of max |G| over one image from its scalars: |dc| <= max|A| (grad-mag) or D (variance), |E - n| <= max|E| + 1.
+// The fixed-point scale of the gradient accumulators needs SOME bound of what is added (grad_shift_pixel / grad_shift); the tie terms
+// k_m, k_M dominate it by orders of magnitude, so this one costs at most a bit against the exact maximum k_imgrad used to measure.
+__device__ __forceinline__ double gbound_from(const GCoef& q, const ImgScal& s, bool gradmag, double amax, double emax) {
+    return 1.0001 * (fabs((double)q.k_c) * (gradmag ? amax : s.D) + fabs((double)q.k_n) * (emax + 1.0) + fabs((double)q.k_m) + fabs((double)q.k_M));
+}
+// G = dL/dIWE at one pixel from (A, E, I): 3 loads + 8 fp32 operations; every gradient evaluation of the composed path and
+// eincm_get_image_grad (k_compose) use this one function, so they see the same image.
+__device__ __forceinline__ float compose_G(const GCoef& q, bool gradmag, float a, float e, float v) {
+    const float dc = gradmag ? a : v - q.meanI;
+    const float n = (v - q.m) * q.invD;
+    float gv = fmaf(q.k_c, dc, q.k_n * (e - n));
+    gv += (v == q.m) ? q.k_m : 0.0f;
+    gv += (v == q.M) ? q.k_M : 0.0f;
+    return gv;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_div: IWE divergence of the normalised IWE (event_collapse_objectives.py:8-20), forward only.
 //   d = mean | K (*) (n (*) Sx) + K (*) (n (*) Sy) | = mean | K (*) (gx_n + gy_n) |, every stage zero padded.
 // grid (ntiles, R, B); writes one partial sum per tile.
@@ -1065,7 +1238,7 @@ __global__ __launch_bounds__(NT) void k_div(Geom g, const float* __restrict__ iw
     const int x0 = tx * TS, y0 = ty * TS;
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
     if (threadIdx.x < 64) {
-        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
+        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.pstride, g.nparts);
         if (threadIdx.x == 0) { sc[0] = s.m; sc[1] = s.D; }
     }
     __syncthreads();
@@ -1121,7 +1294,7 @@ __global__ __launch_bounds__(NT) void k_divgrad(Geom g, const float* __restrict_
     const int x0 = tx * TS, y0 = ty * TS;
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
     if (threadIdx.x < 64) {
-        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
+        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.pstride, g.nparts);
         if (threadIdx.x == 0) { sc[0] = s.m; sc[1] = s.D; }
     }
     __syncthreads();
@@ -1192,7 +1365,8 @@ __global__ __launch_bounds__(NT) void k_divgrad(Geom g, const float* __restrict_
 
 // dL/dw of one event at one reference time: the event is warped like in the forward pass, its 3x3 neighbourhood of G = dL/dIWE is
 // read from the LDS window `lds` (bounding box wn; taps outside it straight from the image Gi with the JAX wrap/drop rule).
-__device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, const float* lds, const float* __restrict__ Gi,
+template <typename GAt>      // GAt: float operator()(size_t pixel) - dL/dIWE of this (window, reference time) at a pixel of the image
+__device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, const float* lds, const GAt& Gi,
                                            int x, int y, double2 v, double dt, float& gwx, float& gwy) {
     int irx, iry; float fx, fy;
     warp_axis(x, v.x, dt, irx, fx);
@@ -1229,7 +1403,7 @@ __device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, cons
                     val = lds[cy * wn.ww + cx];
                 } else {
                     const int gx = wrap_drop(sx - 1 + dx, g.W), gy = wrap_drop(sy - 1 + dy, g.H);
-                    if (gx >= 0 && gy >= 0) val = Gi[(size_t)gy * g.W + gx];
+                    if (gx >= 0 && gy >= 0) val = Gi((size_t)gy * g.W + gx);
                 }
                 gv[dy][dx] = val;
             }
@@ -1258,62 +1432,123 @@ __device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, cons
 // slots in index order).  Otherwise: per-pixel sums are accumulated in an LDS copy of the source tile as i64 fixed point
 // (ds_add_u64; scale grad_shift_pixel) and flushed with i64 global atomics.  Both are bit-reproducible.
 // ------------------------------------------------------------------------------------------------
-template <int TM, int WIDE, int NTH>      // NTH threads per workgroup: 256, or 512 where the LDS footprint allows only 3 workgroups per CU (THETA_TILE); TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
+template <int TM, int WIDE, int NTH, int COMPOSE>      // NTH threads per workgroup: 256, or 512 where the LDS footprint allows only 3 workgroups per CU (THETA_TILE); TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
 __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WIDE: 61-bit fixed point per event (tiny windows, see grad_shift_pixel)
         const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
         const double* __restrict__ Theta, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
-        const float* __restrict__ G,           // (B,R,H,W)
+        const float* __restrict__ G,           // (B,R,H,W) dL/dIWE written by k_imgrad (COMPOSE = 0), or the A image of k_imstat (COMPOSE = 1)
         const Window* __restrict__ wins,       // (n_items, R) windows of this evaluation
         long long* __restrict__ gTheta,        // (B,H,W,2) i64 fixed point, zero on entry (cleared by its consumer)
         int direct11, double* __restrict__ g11,                     // 2-DoF theta: (n_items, R, 2) per-workgroup partials of dL/dtheta
-        const WinConst* __restrict__ wc, const unsigned* __restrict__ gmax,   // scale of the i64 accumulators (grad_shift)
-        int theta_mode, const int32_t* __restrict__ order)
+        const WinConst* __restrict__ wc, unsigned* __restrict__ gmax,   // scale of the i64 accumulators (grad_shift): read (COMPOSE = 0) or written
+        int theta_mode, const int32_t* __restrict__ order,
+        int use_arg, const double* __restrict__ theta_c, ThetaArg targ,   // 2-DoF theta (B,2): in the kernel arguments, or behind theta_c
+        // COMPOSE = 1 (k_imstat in front instead of k_stats_stream + k_imgrad): G is composed from (A, E, I) while the window is staged
+        EvalParams ep, const float* __restrict__ edges, const float* __restrict__ iwe, const StatPart* __restrict__ parts,
+        const unsigned* __restrict__ amax,
+        unsigned long long* __restrict__ acc,  // the u64 IWE accumulator: consumed by k_imstat, cleared here (a slice per workgroup)
+        const int32_t* __restrict__ win_item0, double* __restrict__ imgscal_out)   // 2-DoF: the first workgroup of a window hands the image scalars to the host
 {
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
     if (TM != 0) direct11 = (TM == THETA_CONST) ? 1 : 0;     // the host ties the two (2-DoF theta <=> per-workgroup partials)
     // LDS: [G window: wincap floats][accum: TS*TS*2 doubles unless direct11][Theta tile: TS*TS double2 if THETA_TILE]
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red11[NTH / 64];
+    __shared__ GCoef sq[COMPOSE ? 16 : 1];
+    __shared__ double sbound[COMPOSE ? 16 : 2];
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(lds + g.wincap);   // i64 fixed point: ds_add_u64 (3.7 lane-ops/clk/CU; ds_add_f32: 0.33)
     double2* thtile = reinterpret_cast<double2*>(lds + g.wincap + (direct11 ? 0 : TS * TS * 4));
     float f11x = 0.0f, f11y = 0.0f;             // direct11: this thread's share of sum_e -dt * dL/dw
+    if (COMPOSE) {
+        // consumer-clears, delegated: k_imstat has read the accumulator (halos included), so every workgroup of this launch zeroes
+        // an equal share of it with plain stores (fire and forget; nothing in this kernel reads it)
+        const size_t total = (size_t)g.B * g.R * g.H * g.W;
+        const size_t lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
+        for (size_t i = lo + threadIdx.x; i < hi; i += NTH) acc[i] = 0ull;
+    }
     int item, r;
     if (!block_to_work(n_items, g.R, order, item, r)) return;
     const Item it = items[item];
     const double tau = edge_ts[it.win * g.R + r];
-    const Window wn = wins[(size_t)item * g.R + r];
-    const float* __restrict__ Gi = G + ((size_t)it.win * g.R + r) * g.H * g.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {      // the usual case: window inside the image
-        const float* __restrict__ src = Gi + (size_t)wn.oy * g.W + wn.ox;
-        for (WinWalkT<NTH> w(threadIdx.x, wn.ww); w.i < wn.ww * wn.wh; w.next()) lds[w.i] = src[w.row * g.W + w.col];
-    } else {
-        for (int row = wv; row < wn.wh; row += NTH / 64) {
-            const int gy = wrap_drop(wn.oy + row, g.H);
-            for (int col = lane; col < wn.ww; col += 64) {
-                const int gx = wrap_drop(wn.ox + col, g.W);
-                lds[row * wn.ww + col] = (gx >= 0 && gy >= 0) ? Gi[(size_t)gy * g.W + gx] : 0.0f;
+    const bool gradmag = (ep.contrast_kind == 0);
+    if (COMPOSE) {
+        // the image scalars: 2-DoF theta needs those of its own reference time; a theta grid also the bound of |G| over all R
+        // images of the window (the scale of its i64 accumulators), so its waves take the reference times side by side
+        const double HW = (double)g.H * (double)g.W;
+        const WinConst& c = wc[it.win];
+        for (int rr = direct11 ? (wv == 0 ? r : g.R) : wv; rr < g.R; rr += direct11 ? g.R : NTH / 64) {
+            const size_t slot = ((size_t)it.win * g.R + rr) * g.pstride;
+            const ImgScal s = reduce_parts(parts + slot, g.nparts);
+            unsigned am = 0u;
+            for (int i = lane; i < g.nparts; i += 64) am = max(am, amax[slot + i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, o, 64));
+            if (lane == 0) {
+                const GCoef q = gcoef_from(s, c, ep, rr, g.R, HW);
+                sq[rr] = q;
+                sbound[rr] = gbound_from(q, s, gradmag, (double)__uint_as_float(am), c.eabs[rr]);
+                if (imgscal_out && rr == r && item == win_item0[it.win]) {
+                    double* o = imgscal_out + ((size_t)it.win * g.R + r) * IMGSCAL_N;
+                    o[0] = s.m; o[1] = s.M; o[2] = s.D; o[3] = s.cm; o[4] = s.cM; o[5] = s.sI; o[6] = s.sII; o[7] = s.sEI; o[8] = s.sG2;
+                }
             }
         }
     }
-    double gscale = 0.0;                          // 2^eg of this window's gradient accumulators
-    if (!direct11) {
-        __shared__ unsigned gms[NTH / 64];
-        for (int i = threadIdx.x; i < TS * TS * 2; i += NTH) accum[i] = 0ull;
-        gscale = ldexp(1.0, grad_shift_pixel(wc[it.win], gmax_of(gmax + (size_t)it.win * g.R * g.nig, g.R * g.nig, gms), g.R, WIDE != 0));
+    double2 vconst = make_double2(0.0, 0.0);
+    Window wn;
+    if (theta_mode == THETA_CONST) {              // the same window k_splat derived for itself (see there)
+        vconst = use_arg ? make_double2(targ.v[2 * it.win], targ.v[2 * it.win + 1]) : make_double2(theta_c[2 * it.win], theta_c[2 * it.win + 1]);
+        const double mm4[4] = {vconst.x, vconst.x, vconst.y, vconst.y};
+        wn = item_window(g, it, mm4, tau);
+    } else {
+        wn = wins[(size_t)item * g.R + r];
     }
+    const size_t img = ((size_t)it.win * g.R + r) * g.H * g.W;
+    const float* __restrict__ Gi = G + img;
+    const float* __restrict__ Ei = edges + img;
+    const float* __restrict__ Ii = iwe + img;
     const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
-    double2 vconst = make_double2(0.0, 0.0);
-    if (theta_mode == THETA_CONST) {
-        const double* mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
-        vconst = make_double2(mm[0], mm[2]);
-    } else {
+    if (theta_mode != THETA_CONST) {
         const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
         for (int p = threadIdx.x; p < TS * TS; p += NTH) {
             const int y = y0 + p / TS, x = x0 + p % TS;
             thtile[p] = (y < g.H && x < g.W) ? *reinterpret_cast<const double2*>(ThW + ((size_t)y * g.W + x) * 2) : make_double2(0.0, 0.0);
         }
+    }
+    if (!direct11) for (int i = threadIdx.x; i < TS * TS * 2; i += NTH) accum[i] = 0ull;
+    if (COMPOSE) __syncthreads();                 // sq / sbound are complete
+    const GCoef q = sq[COMPOSE ? r : 0];
+    auto G_at = [&](size_t p) -> float {          // dL/dIWE at pixel p of this (window, reference time)
+        if (COMPOSE) return compose_G(q, gradmag, gradmag ? Gi[p] : 0.0f, Ei[p], Ii[p]);
+        return Gi[p];
+    };
+    if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {      // the usual case: window inside the image
+        const size_t o0 = (size_t)wn.oy * g.W + wn.ox;
+        for (WinWalkT<NTH> w(threadIdx.x, wn.ww); w.i < wn.ww * wn.wh; w.next()) lds[w.i] = G_at(o0 + w.row * g.W + w.col);
+    } else {
+        for (int row = wv; row < wn.wh; row += NTH / 64) {
+            const int gy = wrap_drop(wn.oy + row, g.H);
+            for (int col = lane; col < wn.ww; col += 64) {
+                const int gx = wrap_drop(wn.ox + col, g.W);
+                lds[row * wn.ww + col] = (gx >= 0 && gy >= 0) ? G_at((size_t)gy * g.W + gx) : 0.0f;
+            }
+        }
+    }
+    double gscale = 0.0;                          // 2^eg of this window's gradient accumulators
+    if (!direct11) {
+        double gm;
+        if (COMPOSE) {
+            gm = sbound[0];
+            for (int rr = 1; rr < g.R; ++rr) gm = fmax(gm, sbound[rr]);
+            gm = (double)(float)gm;               // the consumers of the accumulators (k_project, k_final*) read it back as a float
+            if (threadIdx.x == 0 && r == 0) gmax[it.win] = __float_as_uint((float)gm);      // every workgroup of the window writes the same bits
+        } else {
+            __shared__ unsigned gms[NTH / 64];
+            gm = gmax_of(gmax + (size_t)it.win * g.gmax_n, g.gmax_n, gms);
+        }
+        gscale = ldexp(1.0, grad_shift_pixel(wc[it.win], gm, g.R, WIDE != 0));
     }
     __syncthreads();
 
@@ -1326,7 +1561,7 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         const int x = ev.xy & 0xffff, y = ev.xy >> 16;
         const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)];
         float gwx, gwy;
-        event_dLdw(g, wn, lds, Gi, x, y, v, dt, gwx, gwy);
+        event_dLdw(g, wn, lds, G_at, x, y, v, dt, gwx, gwy);
         if (direct11) {          // theta (1,1,2): Theta is constant, dL/dtheta = sum over all events; no per-pixel image needed.
             // fp32 over the thread's own <= 32 terms (their rounding errors are independent across 10^6 threads and average out:
             // measured 1e-9 relative on the gradient), fp64 from there on
@@ -1341,11 +1576,13 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
     };
     // a plain strided loop: with 8 waves per SIMD the loads are hidden by occupancy; the renamed-register pipeline of
     // k_splat measured 2.5 % slower here (133 vs 130 us)
+#ifndef EINCM_ABL_G_NOEVENTS
 #pragma unroll 2
     for (int e = tid; e < n; e += NTH) {
         EvReg ev; ev.xy = exy[e]; ev.t = et[e];
         gather_ev(ev);
     }
+#endif
     if (direct11) {
         double sum11x = block_sum<NTH / 64>((double)f11x, red11);
         double sum11y = block_sum<NTH / 64>((double)f11y, red11);
@@ -1363,6 +1600,26 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         const unsigned long long v = accum[i];
         if (px < tw && py < th && v != 0ull) atomicAdd(gT + ((size_t)(y0 + py) * g.W + (x0 + px)) * 2 + c, v);
     }
+}
+
+// k_compose: dL/dIWE as an image, for eincm_get_image_grad after an evaluation whose gather composed it on the fly (the same
+// compose_G on the same scalars).  grid (blocks, R, B), grid-stride over the pixels of image (b, r).
+__global__ __launch_bounds__(NT) void k_compose(Geom g, EvalParams ep, const float* __restrict__ A, const float* __restrict__ edges,
+                                                 const float* __restrict__ iwe, const StatPart* __restrict__ parts,
+                                                 const WinConst* __restrict__ wc, float* __restrict__ G)
+{
+    __shared__ GCoef sq;
+    const int r = blockIdx.y, b = blockIdx.z;
+    if (threadIdx.x < 64) {
+        const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.pstride, g.nparts);
+        if (threadIdx.x == 0) sq = gcoef_from(s, wc[b], ep, r, g.R, (double)g.H * (double)g.W);
+    }
+    __syncthreads();
+    const GCoef q = sq;
+    const bool gradmag = (ep.contrast_kind == 0);
+    const size_t n = (size_t)g.H * g.W, img = ((size_t)b * g.R + r) * n;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT)
+        G[img + i] = compose_G(q, gradmag, gradmag ? A[img + i] : 0.0f, edges[img + i], iwe[img + i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1613,7 +1870,7 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
         }
     }
     __shared__ unsigned gms[NWAVE];
-    const double gm = gmax_of(gmax + (size_t)b * g.R * g.nig, g.R * g.nig, gms);       // independent of the rest: its loads go first
+    const double gm = gmax_of(gmax + (size_t)b * g.gmax_n, g.gmax_n, gms);       // independent of the rest: its loads go first
     const ResampleTile rs = stage_resample_ranges(RL, h, w, x0, y0, x1, y1, rowtap, coltap);
     stage_resample_weights(RL, rs, h, w, x0, y0, x1, y1, AH, AW);
     const int ilo = rs.ilo, jlo = rs.jlo, ni = rs.ni, nj = rs.nj, ncell = ni * nj;
@@ -1791,7 +2048,7 @@ __global__ __launch_bounds__(FT) void k_final(Geom g, EvalParams ep,
                 for (int i = lane; i < g.nig; i += 64) v += g2parts[((size_t)b * g.R + r) * g.nig + i];
                 g2sum = __shfl(wave_sum(v), 0, 64);
             }
-            const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.ntiles, g.nparts);
+            const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.pstride, g.nparts);
             if (lane == 0) {
                 const double mse = mse_from_moments(s, c.sE[r], c.sEE[r], HW);
                 const double mean = s.sI / HW;
@@ -1860,7 +2117,7 @@ __global__ __launch_bounds__(FT) void k_final(Geom g, EvalParams ep,
             }
         } else {
             __shared__ unsigned gms[FW];
-            const double inv = ldexp(1.0, -grad_shift(c, gmax_of(gmax + (size_t)b * g.R * g.nig, g.R * g.nig, gms), g.R));
+            const double inv = ldexp(1.0, -grad_shift(c, gmax_of(gmax + (size_t)b * g.gmax_n, g.gmax_n, gms), g.R));
             for (int i = threadIdx.x; i < n; i += FT) {
                 double v = (double)gth_main[(size_t)b * gth_cap + i] * inv;
                 gth_main[(size_t)b * gth_cap + i] = 0;
@@ -1880,7 +2137,7 @@ __global__ void k_final_dense(Geom g, int use_tv, int wide, long long* __restric
     const size_t n = (size_t)g.H * g.W * 2;
     const double s = outs[b].tv_scale;
     __shared__ unsigned gms[NWAVE];
-    const double inv = ldexp(1.0, -grad_shift_pixel(wc[b], gmax_of(gmax + (size_t)b * g.R * g.nig, g.R * g.nig, gms), g.R, wide != 0));
+    const double inv = ldexp(1.0, -grad_shift_pixel(wc[b], gmax_of(gmax + (size_t)b * g.gmax_n, g.gmax_n, gms), g.R, wide != 0));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const long long q = gTheta[b * n + i];
         if (q != 0) gTheta[b * n + i] = 0;

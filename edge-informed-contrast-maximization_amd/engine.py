@@ -337,6 +337,12 @@ class Engine:
         d['total'] = float(t.total_ms)
         return d, int(n.value)
 
+    def host_profile(self, reset=False):
+        """(dict of host-side microseconds per evaluation phase summed since the last reset, number of evaluations)."""
+        us = (C.c_double * 4)(); n = C.c_int64(0)
+        self._check(self._lib.eincm_get_host_profile(self._ctx, us, C.byref(n), 1 if reset else 0))
+        return dict(zip(('begin', 'launch', 'wait', 'collect'), (float(v) for v in us))), int(n.value)
+
     def set_timed_kernels(self, splat=True, gather=True):
         """timing='dominant' contexts: which event kernels carry HIP timing events from the next evaluation on."""
         self._check(self._lib.eincm_set_timed_kernels(self._ctx, 1 if splat else 0, 1 if gather else 0))

@@ -201,6 +201,17 @@ int eincm_get_timings(eincm_ctx* ctx, eincm_timings* t);
 /* EINCM_CF_TIMING_DOMINANT contexts: which of the two event kernels carry timing events from the next evaluation on (both by
  * default).  A timed launch costs ~6 us of an evaluation; a throughput measurement times only the kernel it reports. */
 int eincm_set_timed_kernels(eincm_ctx* ctx, int splat, int gather);
+
+/* Host-side wall time (microseconds, summed since the last reset) the calling thread spent in the phases of the evaluations of
+ * this context, and their number: [EINCM_HP_BEGIN] argument checks, theta staging and the launches of the forward half,
+ * [EINCM_HP_LAUNCH] the launches of the second half, [EINCM_HP_WAIT] waiting for the stream, [EINCM_HP_COLLECT] handing the
+ * results over (incl. the host-side scalar assembly of 2-DoF evaluations).  A diagnostic: what an evaluation costs besides its kernels. */
+#define EINCM_HP_BEGIN 0
+#define EINCM_HP_LAUNCH 1
+#define EINCM_HP_WAIT 2
+#define EINCM_HP_COLLECT 3
+#define EINCM_N_HOST_PHASES 4
+int eincm_get_host_profile(eincm_ctx* ctx, double* us /* EINCM_N_HOST_PHASES */, int64_t* n_evals, int reset);
 /* sums of the per-evaluation timings since the last reset, and how many evaluations they cover (a bench reads them once after
  * its timed loop instead of calling eincm_get_timings inside it) */
 int eincm_get_timings_total(eincm_ctx* ctx, eincm_timings* sum, int64_t* n_evals, int reset);

@@ -550,3 +550,67 @@ def test_long_splat_segments_use_two_lds_windows(monkeypatch):
         assert abs(v[0] - v_ref) <= TOL * abs(v_ref)
         assert rel(g[0], g_ref) <= TOL
         assert rel(eng.iwes()[0], aux['_iwes']) <= TOL
+
+
+def fma_tie_events(v, W, n_want, rng):
+    """Events (x, t) for which fl(x - fl(v*t)) sits exactly on a half-integer while the unrounded x - v*t does not, chosen so that
+    the two round to DIFFERENT pixels: what a fused multiply-add (one rounding) gets wrong against the reference's two roundings
+    (/root/reference/src/eincm/event_warpers.py:34, `xs - theta * dts * delta_time`).  Exact arithmetic with fractions."""
+    from fractions import Fraction
+    xs, ts = [], []
+    fv = Fraction(v)
+    for m in (int(q) for q in rng.permutation(np.arange(8, W - 8))):
+        p = float(m) + 0.5                              # the rounded product we want: a half-integer
+        t0 = p / v
+        for t in (t0, np.nextafter(t0, 0.0), np.nextafter(t0, 2.0)):
+            if not (0.0 < t <= 1.0) or v * t != p:
+                continue
+            eps = fv * Fraction(t) - Fraction(p)        # exact product minus its fp64 rounding
+            if eps == 0:
+                continue
+            for k in (2, 3, 4, 5):                      # w = x - p = k + 0.5: half-to-even gives k (k even) or k + 1 (k odd)
+                x = m + k + 1                           # x - (m + 0.5) = k + 0.5
+                if x >= W:
+                    continue
+                w_two = float(x) - v * t                # numpy / the reference: product rounded first
+                exact = Fraction(x) - fv * Fraction(t)
+                r_two = int(np.rint(w_two))
+                r_fma = int(np.rint(float(exact)))      # float(Fraction) rounds once, like an FMA
+                if w_two == k + 0.5 and r_fma != r_two:
+                    xs.append(x); ts.append(t)
+                    break
+            break
+        if len(xs) >= n_want:
+            break
+    return np.array(xs, dtype=np.int16), np.array(ts, dtype=np.float64)
+
+
+def test_warp_rounds_the_product_first():
+    """The integer-deciding code performs the reference's two roundings, w = fl(x - fl(theta*dt)), not one fused multiply-add:
+    on events constructed so that the two disagree about rint(w), the rounded-coordinate count image equals the oracle's bit for
+    bit (with `x - v*dt` contracted to v_fma_f64 every one of these events lands one pixel off)."""
+    H, W, R = 48, 346, 1
+    rng = np.random.default_rng(11)
+    v = 297.3187654321                                   # px per window along x; dt = t - 0
+    xs_c, ts_c = fma_tie_events(v, W, 60, rng)
+    assert len(xs_c) >= 40, 'construction found too few FMA-sensitive events'
+    n_bg = 4000                                          # background events so that the window is an ordinary one
+    xs = np.concatenate([xs_c, rng.integers(0, W, n_bg).astype(np.int16)])
+    ts = np.concatenate([ts_c, rng.random(n_bg)])
+    ys = rng.integers(0, H, len(xs)).astype(np.int16)
+    order = np.argsort(ts, kind='stable'); xs, ys, ts = xs[order], ys[order], ts[order]
+    edges = rng.random((R, H, W)); edge_ts = np.array([0.0])
+    th = np.array([v, 0.0]).reshape(1, 1, 2)
+    Theta = O.scale_theta_to_sensor_size(th, (H, W))
+    wx, wy = O.per_pix_warp(Theta, xs, ys, ts, edge_ts[0])
+    ref = O.rounded_count_image(wx, wy, (H, W))
+    with engine.Engine((H, W), len(xs), max_refs=R) as eng:
+        eng.set_window(xs, ys, ts, edges, edge_ts)
+        eng.loss_grad(th, engine.make_params(20.0, 35.0, 0.0, 0.0, 4), want_grad=False)
+        cnt = eng.count_images()[0]
+        assert np.array_equal(cnt[0].astype(np.int64), ref), f'{np.count_nonzero(cnt[0] != ref)} pixels differ'
+        # the float path sees the same decisions: IWE and gradient against the oracle
+        v_ref, g_ref, aux = O.loss_and_grad(th, xs, ys, ts, edges, edge_ts, 20.0, 35.0, 0.0, 0.0, 4, 5, (H, W), return_intermediates=True)
+        vv, g, _ = eng.loss_grad(th, engine.make_params(20.0, 35.0, 0.0, 0.0, 4))
+        assert abs(vv[0] - v_ref) <= TOL * abs(v_ref)
+        assert rel(eng.iwes()[0], aux['_iwes']) <= TOL

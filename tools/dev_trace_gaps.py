@@ -4,14 +4,17 @@ import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].split('::')[-1]) for r in csv.DictReader(open(f))]
 rows.sort()
-# an evaluation starts at k_theta
+# an evaluation starts at k_theta*, or at a k_splat that no k_theta* precedes (2-DoF theta: the event kernels derive their windows themselves)
 evals, cur = [], []
 for s, e, n in rows:
-    if n.startswith('k_theta') and cur:
+    first = n.startswith('k_theta') or (n.startswith('k_splat') and not (cur and cur[-1][2].startswith('k_theta')))
+    if first and cur:
         evals.append(cur); cur = []
     cur.append((s, e, n))
 evals.append(cur)
-evals = [ev for ev in evals if ev[0][2].startswith('k_theta')][-100:]
+evals = [ev for ev in evals if ev[0][2].startswith(('k_theta', 'k_splat'))]
+nk = max(set(len(ev) for ev in evals), key=[len(ev) for ev in evals].count)       # the usual number of kernels per evaluation
+evals = [ev for ev in evals if len(ev) == nk][-100:]
 dur, gap = collections.defaultdict(list), collections.defaultdict(list)
 span = []
 for ev in evals:

@@ -15,3 +15,7 @@ with engine.Engine((H, W), N, max_refs=R) as e:
     for k in range(100):
         t0 = time.perf_counter(); e.loss_grad(th * (1 + .01 * (k % 5)), p); ts.append(time.perf_counter() - t0)
     print(f'N={N} theta=({h},{h}) wall median {np.median(ts)*1e6:.1f} us min {min(ts)*1e6:.1f} us')
+    e.host_profile(reset=True)
+    for k in range(200): e.loss_grad(th * (1 + .01 * (k % 5)), p)
+    hp, n = e.host_profile()
+    print('host phases, us per evaluation: ' + ', '.join(f'{k} {v / n:.1f}' for k, v in hp.items()))
