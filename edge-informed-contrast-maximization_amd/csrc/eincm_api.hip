@@ -94,7 +94,9 @@ struct eincm_ctx {
     unsigned* d_gmax = nullptr;    // (B,R,nig) per-strip max |dL/dIWE| as float bits (scale of the i64 gradient accumulators)
     unsigned* d_cntmax = nullptr;  // (B) staging scratch: most events on one source pixel
     unsigned* d_amax = nullptr;    // (B,R,pstride) max |A| per k_imstat workgroup (float bits)
-    unsigned* d_gbound = nullptr;  // (B) bound of max |dL/dIWE| written by the composing gather (float bits): what gmax is when gmax_n == 1
+    unsigned* d_gbound = nullptr;  // (B,R) bound of max |dL/dIWE| per image from k_imstat's tail (float bits): what gmax is when gmax_n == R
+    unsigned* d_ticket = nullptr;  // (B,R) arrival counters of k_imstat, zero between launches
+    ImgCoef* d_coef = nullptr;     // (B,R) what the gather composes dL/dIWE with
     float* d_Gimg = nullptr;       // (B,R,H,W) dL/dIWE materialised for eincm_get_image_grad after a composed evaluation (allocated on demand)
     bool last_composed = false;    // the last gradient evaluation left A in d_G (the gather composed dL/dIWE on the fly)
     EvalParams last_ep{};
@@ -263,7 +265,7 @@ void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_items_s); F(c->d_order); F(c->d_order_s); F(c->d_wins); F(c->d_wins_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
     F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_itembase_s); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_acc); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
-    F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax); F(c->d_cntmax); F(c->d_amax); F(c->d_gbound); F(c->d_Gimg);
+    F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax); F(c->d_cntmax); F(c->d_amax); F(c->d_gbound); F(c->d_ticket); F(c->d_coef); F(c->d_Gimg);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
     F(c->d_divparts); F(c->d_g2parts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
     F(c->d_rowtap); F(c->d_coltap);
@@ -568,10 +570,20 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         if (c->seg_s_used > c->chunk) cap = std::min(cap, 4608);
         c->g.wincap = cap;
         c->g.winmaxw = std::max(40, (int)std::lround(std::sqrt((double)cap * 1.4)));
+        // the gather's own list: longer segments see a longer time span, hence a larger displacement spread; a window too small for it
+        // sends taps down the direct path, where a composed dL/dIWE costs three loads per tap
+        const double tspan_a = std::min(1.0, (double)c->seg_used / std::max(per_tile, 1.0));
+        const double side_a = TS + 4 + vmax * tspan_a;
+        int cap_a = caps[3];
+        for (int k = 0; k < 4; ++k) if (side_a * side_a <= caps[k]) { cap_a = caps[k]; break; }
+        cap_a = std::max(cap_a, cap);
+        c->g.wincap_a = cap_a;
+        c->g.winmaxw_a = std::max(40, (int)std::lround(std::sqrt((double)cap_a * 1.4)));
     }
     // 2-DoF theta with nothing but the contrast and correlation terms (every level above 0 of the reference's pyramid at its first
     // level, and the bench workload): the scalar assembly and the sum of the gather's per-workgroup partials run on the host
-    const bool host_asm = want_grad && !identity && h == 1 && w == 1 && !ep.want_div && !ep.want_tv && !full_aux && !getenv("EINCM_NO_HOST_ASM");
+    static const bool no_host_asm = getenv("EINCM_NO_HOST_ASM") != nullptr;
+    const bool host_asm = want_grad && !identity && h == 1 && w == 1 && !ep.want_div && !ep.want_tv && !full_aux && !no_host_asm;
     if (host_asm) {
         c->theta_nan.assign((size_t)g.B, 0);
         for (int b = 0; b < g.B; ++b) c->theta_nan[b] = !(std::isfinite(theta_host[2 * b]) && std::isfinite(theta_host[2 * b + 1]));
@@ -596,16 +608,20 @@ int eval_end_launch(eincm_ctx* c) {
     const size_t nth = (size_t)h * w * 2;
     const bool timing = (c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)) != 0;
     const bool host_asm = c->pend.host_asm;
-    // The image pass of a gradient evaluation: k_imstat (statistics + the stats-independent part of dL/dIWE in one kernel), the gather
-    // composes dL/dIWE while staging its windows.  delta != 0 needs the divergence adjoint image in between: k_stats_stream / k_stats,
-    // k_divgrad, k_imgrad and a gather that reads the finished image, as do forward-only evaluations (no gather to compose in).
-    const bool compose = want_grad && !div_grad && !getenv("EINCM_NO_COMPOSE");
+    // The image pass of a gradient evaluation.  Default: k_stats_stream -> k_imgrad -> gather.  EINCM_COMPOSE=1 selects the fused
+    // form built in round 3: k_imstat (statistics + the stats-independent part of dL/dIWE in one kernel, the per-image scalars in its
+    // tail) and a gather that composes dL/dIWE while staging its windows - one dependent kernel fewer, but measured no faster
+    // (one window of 10^6 events: 72.4 vs 72.2 us; the 8-window batch 236 vs 231 us: the gather pays three loads per window pixel
+    // and k_imstat's tail as much as the kernel boundary it saves), so it stays an option.
+    // delta != 0 and forward-only evaluations always take the unfused kernels.
+    static const bool compose_env = getenv("EINCM_COMPOSE") != nullptr;
+    const bool compose = want_grad && !div_grad && compose_env;
     const bool g2_from_imgrad = !compose && want_grad && ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG;
     const bool zero_copy_out = !identity && (size_t)g.B * nth <= ZERO_COPY_MAX;
     const bool stream_stats = host_asm || (g2_from_imgrad && g.ntiles >= NSPART);
     const int n_imwg = (g.nig + IG_NT / 64 - 1) / (IG_NT / 64);
     unsigned* gmax_buf = compose ? c->d_gbound : c->d_gmax;
-    g.gmax_n = compose ? 1 : g.R * g.nig;
+    g.gmax_n = compose ? g.R : g.R * g.nig;
     c->pend.composed = compose;
     {
         StageTimer t(c, EINCM_STAGE_STATS, compose || stream_stats);
@@ -614,7 +630,8 @@ int eval_end_launch(eincm_ctx* c) {
         if (compose) {
             g.nparts = n_imwg;
             launch_timed(c, EINCM_STAGE_STATS, k_imstat, dim3(n_imwg, g.R, g.B), dim3(IG_NT), 0, g, ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG ? 1 : 0,
-                         c->d_acc, c->d_edges, c->d_iwe, c->d_G, c->d_parts, c->d_amax);
+                         c->d_acc, c->d_edges, c->d_iwe, c->d_G, c->d_parts, c->d_amax, c->d_ticket, ep, c->d_wc, c->d_coef, c->d_gbound,
+                         host_asm ? c->h_img : nullptr);
         } else if (stream_stats) {
             // gradient evaluations with the grad-mag contrast take the contrast energy from k_imgrad (which computes the Scharr
             // images anyway), so the statistics are a pure streaming reduction with NSPART fat partials per image
@@ -668,11 +685,11 @@ int eval_end_launch(eincm_ctx* c) {
                 const Window* wins_g = use_s ? c->d_wins_s : c->d_wins;
                 const int32_t* order_g = use_s ? c->d_order_s : c->d_order;
 #define GATHER_ARGS(NTH) dim3(use_s ? splat_grid(c) : event_grid(c)), dim3(NTH), \
-                    g.wincap * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), \
+                    (use_s ? g.wincap : g.wincap_a) * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), \
                     g, n_g, items_g, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, wins_g, c->d_gTheta, \
                     direct11 ? 1 : 0, host_asm ? c->h_g11 : c->d_g11, c->d_wc, gmax_buf, direct11 ? THETA_CONST : THETA_TILE, order_g, \
                     c->pend.use_arg ? 1 : 0, c->pend.theta_dev, c->pend.targ, \
-                    ep, c->d_edges, c->d_iwe, c->d_parts, c->d_amax, c->d_acc, c->d_win_item0, (host_asm && compose) ? c->h_img : nullptr
+                    ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG ? 1 : 0, c->d_edges, c->d_iwe, c->d_coef, c->d_acc, use_s ? 0 : 1
                 if (direct11) {
                     if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 1>, GATHER_ARGS(NT));
                     else         launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 0>, GATHER_ARGS(NT));
@@ -902,7 +919,8 @@ int store_constants(eincm_ctx* c) {
         wc.c0_gradmag = o.contrast_gm[0];
         wc.c0_var = o.var[0];
         wc.d0 = o.div[0];
-        for (int r = 0; r < g.R; ++r) wc.zc[r] = o.corr[r];     // -MSE(E_r, n0)
+        for (int r = 0; r < g.R; ++r) { wc.zc[r] = o.corr[r]; wc.inv_zc[r] = 1.0 / (wc.zc[r] + EPSN); }     // -MSE(E_r, n0)
+        wc.inv_c0_gradmag = 1.0 / (wc.c0_gradmag + EPSN); wc.inv_c0_var = 1.0 / (wc.c0_var + EPSN);
     }
     HIPCHK(c, hipMemcpyAsync(c->d_wc, c->h_wc, (size_t)g.B * sizeof(WinConst), hipMemcpyHostToDevice, c->stream));
     for (int b = 0; b < g.B; ++b)      // keep the IUE of every window (first reference image of the theta = 0 pass)
@@ -1027,8 +1045,11 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     const size_t pstride = (size_t)std::max(std::max(ntiles, NSPART), (int)((nig + IG_NT / 64 - 1) / (IG_NT / 64)));
     TRY(dalloc(&c->d_parts, B * R * pstride));
     TRY(dalloc(&c->d_amax, B * R * pstride));
-    TRY(dalloc(&c->d_gbound, B));
-    TRY(hipMemset(c->d_gbound, 0, B * sizeof(unsigned)));
+    TRY(dalloc(&c->d_gbound, B * R));
+    TRY(hipMemset(c->d_gbound, 0, B * R * sizeof(unsigned)));
+    TRY(dalloc(&c->d_ticket, B * R));
+    TRY(hipMemset(c->d_ticket, 0, B * R * sizeof(unsigned)));
+    TRY(dalloc(&c->d_coef, B * R));
     TRY(dalloc(&c->d_divparts, B * R * ntiles));
     TRY(dalloc(&c->d_g2parts, B * R * nig));
     TRY(dalloc(&c->d_tvparts, B * ntiles * 3));
@@ -1105,6 +1126,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     g.pstride = std::max(std::max(g.ntiles, NSPART), (g.nig + IG_NT / 64 - 1) / (IG_NT / 64));
     g.gmax_n = g.R * g.nig;
     g.wincap = c->wincap; g.winmaxw = std::max(40, (int)std::lround(std::sqrt((double)c->wincap * 1.4)));
+    g.wincap_a = g.wincap; g.winmaxw_a = g.winmaxw;
 
     // Segment lengths (events per workgroup and reference time), measured on MI355X with the longest-first order of block_to_work
     // (tools/dev_tune_seg.py, profiles/r02/segment_tuning.txt).  Per-workgroup fixed cost (window clear / flush, G-window load,

@@ -62,7 +62,8 @@ constexpr float EXP_M05 = 0.6065306597126334f;   // exp(-1/2)
 struct Geom {
     int H, W, R, B;
     int tilesX, tilesY, ntiles;
-    int wincap, winmaxw;      // LDS destination-window capacity (pixels) and maximum width of the event kernels
+    int wincap, winmaxw;      // LDS destination-window capacity (pixels) and maximum width: the splat's segment list (items_s, "list b")
+    int wincap_a, winmaxw_a;  // the same for the gather's own list (items, "list a"): its segments are longer, so they span more time and move further
     int nparts;               // StatParts per image written by the statistics kernel of this evaluation (ntiles or NSPART)
     int pstride;              // StatPart slots per image: max(ntiles, NSPART, k_imstat workgroups per image)
     int gmax_n;               // words of `gmax` per window: R * nig per-strip maxima of k_imgrad, or 1 bound written by the composing gather
@@ -89,6 +90,7 @@ struct WinConst {                 // theta-independent constants of a window (lo
     double zc[16];                // zero_corrs[r] = -MSE(E_r, n0)
     double sE[16], sEE[16];       // sum E_r, sum E_r^2
     double eabs[16];              // max |E_r| (bounds dL/dIWE: gbound_from)
+    double inv_c0_gradmag, inv_c0_var, inv_zc[16];   // 1 / (c0 + eps), 1 / (zc[r] + eps): gcoef_from multiplies
     double mrw[16];               // multi-reference weights (losses.py:39-46)
     double dtmax;                 // max |t_e - tau_r| over the window's events and reference times (bounds a gradient term)
     double nev;                   // events staged in this window of this context
@@ -225,7 +227,7 @@ struct Window { int ox, oy, ww, wh; };
 // Destination bounding box of an item at reference time tau: source tile shifted by -v*dt for
 // v in the tile's velocity bounds and dt in the item's time range, +1 for the 3x3 taps, +1 for rounding.
 // Clamped to WIN_CAP floats; taps that fall outside take the (rare) direct-to-HBM path, so ANY box is correct.
-__device__ __forceinline__ Window item_window(const Geom& g, const Item& it, const double* __restrict__ mm4, double tau) {
+__device__ __forceinline__ Window item_window(const Geom& g, const Item& it, const double* __restrict__ mm4, double tau, int wincap, int winmaxw) {
     const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
     const int x1 = min(x0 + TS, g.W) - 1, y1 = min(y0 + TS, g.H) - 1;
@@ -244,9 +246,9 @@ __device__ __forceinline__ Window item_window(const Geom& g, const Item& it, con
     int bx0 = x0 + (int)lo[0] - 2, bx1 = x1 + (int)hi[0] + 2;
     int by0 = y0 + (int)lo[1] - 2, by1 = y1 + (int)hi[1] + 2;
     int ww = bx1 - bx0 + 1, wh = by1 - by0 + 1;
-    if (ww * wh > g.wincap || ww > g.winmaxw) {
-        const int nww = min(ww, g.winmaxw);
-        const int nwh = min(wh, g.wincap / nww);
+    if (ww * wh > wincap || ww > winmaxw) {
+        const int nww = min(ww, winmaxw);
+        const int nwh = min(wh, wincap / nww);
         bx0 = (bx0 + bx1) / 2 - nww / 2;
         by0 = (by0 + by1) / 2 - nwh / 2;
         ww = nww; wh = nwh;
@@ -262,7 +264,9 @@ __device__ __forceinline__ void warp_axis(int x, double v, double dt, int& ir, f
     // no FMA contraction: the reference rounds the product theta * dt before the subtraction (event_warpers.py:34-35; XLA's CPU
     // backend does not contract without fast-math, numpy cannot).  fma(-v, dt, x) differs from that in the last bit of w, which
     // decides rint() for events within 1e-16 relative of a half-integer (tests/test_gpu_parity.py::test_warp_rounds_the_product_first).
+#ifndef EINCM_ABL_WARP_FMA                 // timing-only build: what the second rounding costs (profiles/r03/warp_rounding_cost.txt)
 #pragma clang fp contract(off)
+#endif
     const double w = (double)x - v * dt;
     const double r = rint(w);
     f = (float)(w - r);                              // garbage when the event is off-sensor, but then every tap is dropped
@@ -481,7 +485,8 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
         const int kk = first ? k : k - na;
         const int item = (first ? a0 : b0) + kk / g.R, r = kk % g.R;
         const Item it = (first ? items_a : items_b)[item];
-        (first ? wins_a : wins_b)[(size_t)item * g.R + r] = item_window(g, it, mm4, edge_ts[it.win * g.R + r]);
+        (first ? wins_a : wins_b)[(size_t)item * g.R + r] = item_window(g, it, mm4, edge_ts[it.win * g.R + r], first ? g.wincap_a : g.wincap,
+                                                                          first ? g.winmaxw_a : g.winmaxw);
     }
 }
 
@@ -504,7 +509,7 @@ __device__ __forceinline__ void windows_of(const Geom& g, int idx, int n_a, cons
         const double* mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
         mm4[0] = mm[0]; mm4[1] = mm[1]; mm4[2] = mm[2]; mm4[3] = mm[3];
     }
-    (first ? wins_a : wins_b)[k] = item_window(g, it, mm4, edge_ts[it.win * g.R + r]);
+    (first ? wins_a : wins_b)[k] = item_window(g, it, mm4, edge_ts[it.win * g.R + r], first ? g.wincap_a : g.wincap, first ? g.winmaxw_a : g.winmaxw);
 }
 
 // 2-DoF theta (1,1,2): Theta is one constant per window, so the velocity bounds of every tile are that constant; no image is
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         // launch in front of the splat, no table): ~150 uniform instructions against a dependent kernel boundary per evaluation
         vconst = use_arg ? make_double2(targ.v[2 * it.win], targ.v[2 * it.win + 1]) : make_double2(theta_c[2 * it.win], theta_c[2 * it.win + 1]);
         const double mm4[4] = {vconst.x, vconst.x, vconst.y, vconst.y};
-        wn = item_window(g, it, mm4, tau);
+        wn = item_window(g, it, mm4, tau, g.wincap, g.winmaxw);
     } else {
         const double* __restrict__ ThW = Theta + (size_t)it.win * g.H * g.W * 2;
         for (int p = threadIdx.x; p < TS * TS; p += NTH) {
@@ -1071,6 +1076,50 @@ __global__ __launch_bounds__(IG_NT) void k_imgrad(Geom g, EvalParams ep,
     }
 }
 
+// The per-image scalars G is composed from (see k_imstat), in the precision the composition runs in (fp32 like the image itself;
+// the fp64 originals are the formulas of k_imgrad).  gradmag = 0: the variance contrast, dc = I - mean I.
+struct GCoef { float m, M, invD, k_c, k_n, k_m, k_M, meanI; };
+struct ImgCoef { GCoef q; float bound; float pad_[7]; };      // one 64-byte record per image: what the gather loads (uniformly: scalar registers)
+__device__ __forceinline__ GCoef gcoef_from(const ImgScal& s, const WinConst& c, const EvalParams& ep, int r, int R, double HW) {
+    // Three divisions (1/D and the two tie counts): the window constants come as reciprocals (WinConst.inv_*), everything else is
+    // multiplied by the one 1/D.  A division costs ~10 instructions and ~8 live registers; a dozen of them interleaved took the
+    // composing gather from 66 to 106 VGPRs (7 -> 4 waves per SIMD).  The results are rounded to fp32 anyway.
+    const double iD = 1.0 / s.D;
+    const double a_r = -ep.alpha * c.mrw[r] * ((ep.contrast_kind == 1) ? c.inv_c0_var : c.inv_c0_gradmag) / (double)R;
+    const double k = -ep.beta * c.mrw[r] * c.inv_zc[r] * (2.0 / ((double)R * HW));
+    const double a = s.m * iD;
+    const double S_n = s.sI * iD - HW * a;
+    const double S_En = s.sEI * iD - a * c.sE[r];
+    const double S_nn = (s.sII * iD - 2.0 * a * s.sI) * iD + HW * a * a;
+    const double sGn_n = k * (S_En - S_nn);                  // sum Gn*n
+    const double sGn = k * (c.sE[r] - S_n);                  // sum Gn
+    GCoef q;
+    q.m = (float)s.m; q.M = (float)s.M;                      // exact: extrema of fp32 pixels
+    q.invD = (float)iD;
+    q.k_c = (float)(a_r * (2.0 / HW));
+    q.k_n = (float)(k * iD);
+    q.k_m = (float)(((sGn_n - sGn) * iD) / s.cm);            // dm / #argmin
+    q.k_M = (float)((-sGn_n * iD) / s.cM);                   // dM / #argmax
+    q.meanI = (float)(s.sI * (1.0 / HW));
+    return q;
+}
+// An upper bound of max |G| over one image from its scalars: |dc| <= max|A| (grad-mag) or D (variance), |E - n| <= max|E| + 1.
+// The fixed-point scale of the gradient accumulators needs SOME bound of what is added (grad_shift_pixel / grad_shift); the tie terms
+// k_m, k_M dominate it by orders of magnitude, so this one costs at most a bit against the exact maximum k_imgrad used to measure.
+__device__ __forceinline__ double gbound_from(const GCoef& q, const ImgScal& s, bool gradmag, double amax, double emax) {
+    return 1.0001 * (fabs((double)q.k_c) * (gradmag ? amax : s.D) + fabs((double)q.k_n) * (emax + 1.0) + fabs((double)q.k_m) + fabs((double)q.k_M));
+}
+// G = dL/dIWE at one pixel from (A, E, I): 3 loads + 8 fp32 operations; every gradient evaluation of the composed path and
+// eincm_get_image_grad (k_compose) use this one function, so they see the same image.
+__device__ __forceinline__ float compose_G(const GCoef& q, bool gradmag, float a, float e, float v) {
+    const float dc = gradmag ? a : v - q.meanI;
+    const float n = (v - q.m) * q.invD;
+    float gv = fmaf(q.k_c, dc, q.k_n * (e - n));
+    gv += (v == q.m) ? q.k_m : 0.0f;
+    gv += (v == q.M) ? q.k_M : 0.0f;
+    return gv;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_imstat: the image pass of a gradient evaluation in ONE kernel (round 3): consumer of the u64 accumulator (exact sum -> fp32 IWE,
 // one rounding), image statistics (min / max with tie counts, sum I, sum I^2, sum E I) and the stats-INDEPENDENT part of dL/dIWE:
@@ -1087,10 +1136,19 @@ __global__ __launch_bounds__(IG_NT) void k_imstat(Geom g, int gradmag,
         const unsigned long long* __restrict__ acc, const float* __restrict__ edges,
         float* __restrict__ iwe, float* __restrict__ A,
         StatPart* __restrict__ parts,          // (B,R,pstride): slot blockIdx.x
-        unsigned* __restrict__ amax)           // (B,R,pstride): max |A| of the workgroup's strips as float bits
+        unsigned* __restrict__ amax,           // (B,R,pstride): max |A| of the workgroup's strips as float bits
+        // the tail: the workgroup of an image that arrives LAST reduces the image's partials and derives what the gather composes
+        // dL/dIWE with (one ImgCoef per image, instead of every gather workgroup doing that in its prologue: there it cost the gather
+        // 40 VGPRs, 7 -> 4 waves per SIMD)
+        unsigned* __restrict__ ticket,         // (B,R) arrival counters, zero between launches (the last arriver resets its own)
+        EvalParams ep, const WinConst* __restrict__ wc,
+        ImgCoef* __restrict__ coef,            // (B,R)
+        unsigned* __restrict__ gbound,         // (B,R) bound of max |dL/dIWE| of the image as float bits (the gmax of a composed evaluation)
+        double* __restrict__ imgscal_out)      // (B,R,IMGSCAL_N) or nullptr: the reduced image scalars for the host (pinned memory)
 {
     __shared__ double red[IG_NT / 64][8];
     __shared__ unsigned redm[IG_NT / 64];
+    __shared__ int s_last;
     const int r = blockIdx.y, b = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * (IG_NT / 64) + wv);   // wave-uniform: row tests stay scalar
     const size_t img = ((size_t)b * g.R + r) * g.H * g.W;
@@ -1174,50 +1232,43 @@ __global__ __launch_bounds__(IG_NT) void k_imstat(Geom g, int gradmag,
             o.sI += red[i][4]; o.sII += red[i][5]; o.sEI += red[i][6]; o.sG2 += red[i][7];
             m = max(m, redm[i]);
         }
-        parts[((size_t)b * g.R + r) * g.pstride + blockIdx.x] = o;
-        amax[((size_t)b * g.R + r) * g.pstride + blockIdx.x] = m;
+        // publish: write-through (agent-scope) stores by this ONE lane, drained, then the ticket (cdna_hip_programming.md Guideline 16, R1)
+        const size_t slot = ((size_t)b * g.R + r) * g.pstride + blockIdx.x;
+        double* po = reinterpret_cast<double*>(parts + slot);
+        const double ov[8] = {o.mn, o.mx, o.cmn, o.cmx, o.sI, o.sII, o.sEI, o.sG2};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) __hip_atomic_store(po + i, ov[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(amax + slot, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned old = __hip_atomic_fetch_add(ticket + b * g.R + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old == gridDim.x - 1u) ? 1 : 0;
+        if (old == gridDim.x - 1u) __hip_atomic_store(ticket + b * g.R + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
-}
-
-// The per-image scalars G is composed from (see k_imstat), in the precision the composition runs in (fp32 like the image itself;
-// the fp64 originals are the formulas of k_imgrad).  gradmag = 0: the variance contrast, dc = I - mean I.
-struct GCoef { float m, M, invD, k_c, k_n, k_m, k_M, meanI; };
-__device__ __forceinline__ GCoef gcoef_from(const ImgScal& s, const WinConst& c, const EvalParams& ep, int r, int R, double HW) {
-    const double c0 = (ep.contrast_kind == 1) ? c.c0_var : c.c0_gradmag;
-    const double a_r = -ep.alpha * c.mrw[r] / ((double)R * (c0 + EPSN));
-    const double b_r = -ep.beta * c.mrw[r] / ((double)R * (c.zc[r] + EPSN));
-    const double a = s.m / s.D;
-    const double S_n = s.sI / s.D - HW * a;
-    const double S_En = s.sEI / s.D - a * c.sE[r];
-    const double S_nn = s.sII / (s.D * s.D) - 2.0 * a * s.sI / s.D + HW * a * a;
-    const double k = b_r * 2.0 / HW;
-    const double sGn_n = k * (S_En - S_nn);                  // sum Gn*n
-    const double sGn = k * (c.sE[r] - S_n);                  // sum Gn
-    GCoef q;
-    q.m = (float)s.m; q.M = (float)s.M;                      // exact: extrema of fp32 pixels
-    q.invD = (float)(1.0 / s.D);
-    q.k_c = (float)(a_r * 2.0 / HW);
-    q.k_n = (float)(k / s.D);
-    q.k_m = (float)(((sGn_n - sGn) / s.D) / s.cm);           // dm / #argmin
-    q.k_M = (float)((-sGn_n / s.D) / s.cM);                  // dM / #argmax
-    q.meanI = (float)(s.sI / HW);
-    return q;
-}
-// An upper bound of max |G| over one image from its scalars: |dc| <= max|A| (grad-mag) or D (variance), |E - n| <= max|E| + 1.
-// The fixed-point scale of the gradient accumulators needs SOME bound of what is added (grad_shift_pixel / grad_shift); the tie terms
-// k_m, k_M dominate it by orders of magnitude, so this one costs at most a bit against the exact maximum k_imgrad used to measure.
-__device__ __forceinline__ double gbound_from(const GCoef& q, const ImgScal& s, bool gradmag, double amax, double emax) {
-    return 1.0001 * (fabs((double)q.k_c) * (gradmag ? amax : s.D) + fabs((double)q.k_n) * (emax + 1.0) + fabs((double)q.k_m) + fabs((double)q.k_M));
-}
-// G = dL/dIWE at one pixel from (A, E, I): 3 loads + 8 fp32 operations; every gradient evaluation of the composed path and
-// eincm_get_image_grad (k_compose) use this one function, so they see the same image.
-__device__ __forceinline__ float compose_G(const GCoef& q, bool gradmag, float a, float e, float v) {
-    const float dc = gradmag ? a : v - q.meanI;
-    const float n = (v - q.m) * q.invD;
-    float gv = fmaf(q.k_c, dc, q.k_n * (e - n));
-    gv += (v == q.m) ? q.k_m : 0.0f;
-    gv += (v == q.M) ? q.k_M : 0.0f;
-    return gv;
+    __syncthreads();
+    if (!s_last) return;                                     // uniform
+    if (threadIdx.x < 64) {                                  // one wave: acquire (this CU's L1 may hold stale lines of the partials), then reduce
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const size_t slot0 = ((size_t)b * g.R + r) * g.pstride;
+        const ImgScal s = reduce_parts(parts + slot0, g.nparts);
+        unsigned am2 = 0u;
+        for (int i = lane; i < g.nparts; i += 64) am2 = max(am2, amax[slot0 + i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) am2 = max(am2, (unsigned)__shfl_xor((int)am2, o, 64));
+        if (lane == 0) {
+            const WinConst& c = wc[b];
+            ImgCoef ic;
+            ic.q = gcoef_from(s, c, ep, r, g.R, (double)g.H * (double)g.W);
+            const float bound = (float)gbound_from(ic.q, s, gradmag != 0, (double)__uint_as_float(am2), c.eabs[r]);
+            ic.bound = bound;
+            coef[b * g.R + r] = ic;
+            gbound[b * g.R + r] = __float_as_uint(bound);
+            if (imgscal_out) {
+                double* o = imgscal_out + ((size_t)b * g.R + r) * IMGSCAL_N;
+                o[0] = s.m; o[1] = s.M; o[2] = s.D; o[3] = s.cm; o[4] = s.cM; o[5] = s.sI; o[6] = s.sII; o[7] = s.sEI; o[8] = s.sG2;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1440,24 +1491,23 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         const Window* __restrict__ wins,       // (n_items, R) windows of this evaluation
         long long* __restrict__ gTheta,        // (B,H,W,2) i64 fixed point, zero on entry (cleared by its consumer)
         int direct11, double* __restrict__ g11,                     // 2-DoF theta: (n_items, R, 2) per-workgroup partials of dL/dtheta
-        const WinConst* __restrict__ wc, unsigned* __restrict__ gmax,   // scale of the i64 accumulators (grad_shift): read (COMPOSE = 0) or written
+        const WinConst* __restrict__ wc, const unsigned* __restrict__ gmax,   // scale of the i64 accumulators (grad_shift), COMPOSE = 0
         int theta_mode, const int32_t* __restrict__ order,
         int use_arg, const double* __restrict__ theta_c, ThetaArg targ,   // 2-DoF theta (B,2): in the kernel arguments, or behind theta_c
         // COMPOSE = 1 (k_imstat in front instead of k_stats_stream + k_imgrad): G is composed from (A, E, I) while the window is staged
-        EvalParams ep, const float* __restrict__ edges, const float* __restrict__ iwe, const StatPart* __restrict__ parts,
-        const unsigned* __restrict__ amax,
+        int gradmag_i, const float* __restrict__ edges, const float* __restrict__ iwe,
+        const ImgCoef* __restrict__ coef,      // (B,R) per-image scalars and |G| bounds from k_imstat's tail
         unsigned long long* __restrict__ acc,  // the u64 IWE accumulator: consumed by k_imstat, cleared here (a slice per workgroup)
-        const int32_t* __restrict__ win_item0, double* __restrict__ imgscal_out)   // 2-DoF: the first workgroup of a window hands the image scalars to the host
+        int list_a)                            // the segments walked are the gather's own list (window capacity wincap_a), not the splat's
 {
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
     if (TM != 0) direct11 = (TM == THETA_CONST) ? 1 : 0;     // the host ties the two (2-DoF theta <=> per-workgroup partials)
+    const int wincap = list_a ? g.wincap_a : g.wincap, winmaxw = list_a ? g.winmaxw_a : g.winmaxw;
     // LDS: [G window: wincap floats][accum: TS*TS*2 doubles unless direct11][Theta tile: TS*TS double2 if THETA_TILE]
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red11[NTH / 64];
-    __shared__ GCoef sq[COMPOSE ? 16 : 1];
-    __shared__ double sbound[COMPOSE ? 16 : 2];
-    unsigned long long* accum = reinterpret_cast<unsigned long long*>(lds + g.wincap);   // i64 fixed point: ds_add_u64 (3.7 lane-ops/clk/CU; ds_add_f32: 0.33)
-    double2* thtile = reinterpret_cast<double2*>(lds + g.wincap + (direct11 ? 0 : TS * TS * 4));
+    unsigned long long* accum = reinterpret_cast<unsigned long long*>(lds + wincap);   // i64 fixed point: ds_add_u64 (3.7 lane-ops/clk/CU; ds_add_f32: 0.33)
+    double2* thtile = reinterpret_cast<double2*>(lds + wincap + (direct11 ? 0 : TS * TS * 4));
     float f11x = 0.0f, f11y = 0.0f;             // direct11: this thread's share of sum_e -dt * dL/dw
     if (COMPOSE) {
         // consumer-clears, delegated: k_imstat has read the accumulator (halos included), so every workgroup of this launch zeroes
@@ -1471,36 +1521,13 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
     const Item it = items[item];
     const double tau = edge_ts[it.win * g.R + r];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const bool gradmag = (ep.contrast_kind == 0);
-    if (COMPOSE) {
-        // the image scalars: 2-DoF theta needs those of its own reference time; a theta grid also the bound of |G| over all R
-        // images of the window (the scale of its i64 accumulators), so its waves take the reference times side by side
-        const double HW = (double)g.H * (double)g.W;
-        const WinConst& c = wc[it.win];
-        for (int rr = direct11 ? (wv == 0 ? r : g.R) : wv; rr < g.R; rr += direct11 ? g.R : NTH / 64) {
-            const size_t slot = ((size_t)it.win * g.R + rr) * g.pstride;
-            const ImgScal s = reduce_parts(parts + slot, g.nparts);
-            unsigned am = 0u;
-            for (int i = lane; i < g.nparts; i += 64) am = max(am, amax[slot + i]);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, o, 64));
-            if (lane == 0) {
-                const GCoef q = gcoef_from(s, c, ep, rr, g.R, HW);
-                sq[rr] = q;
-                sbound[rr] = gbound_from(q, s, gradmag, (double)__uint_as_float(am), c.eabs[rr]);
-                if (imgscal_out && rr == r && item == win_item0[it.win]) {
-                    double* o = imgscal_out + ((size_t)it.win * g.R + r) * IMGSCAL_N;
-                    o[0] = s.m; o[1] = s.M; o[2] = s.D; o[3] = s.cm; o[4] = s.cM; o[5] = s.sI; o[6] = s.sII; o[7] = s.sEI; o[8] = s.sG2;
-                }
-            }
-        }
-    }
+    const bool gradmag = gradmag_i != 0;
     double2 vconst = make_double2(0.0, 0.0);
     Window wn;
     if (theta_mode == THETA_CONST) {              // the same window k_splat derived for itself (see there)
         vconst = use_arg ? make_double2(targ.v[2 * it.win], targ.v[2 * it.win + 1]) : make_double2(theta_c[2 * it.win], theta_c[2 * it.win + 1]);
         const double mm4[4] = {vconst.x, vconst.x, vconst.y, vconst.y};
-        wn = item_window(g, it, mm4, tau);
+        wn = item_window(g, it, mm4, tau, wincap, winmaxw);
     } else {
         wn = wins[(size_t)item * g.R + r];
     }
@@ -1518,11 +1545,16 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         }
     }
     if (!direct11) for (int i = threadIdx.x; i < TS * TS * 2; i += NTH) accum[i] = 0ull;
-    if (COMPOSE) __syncthreads();                 // sq / sbound are complete
-    const GCoef q = sq[COMPOSE ? r : 0];
+    const ImgCoef* __restrict__ cw = coef + (COMPOSE ? it.win * g.R : 0);
+    GCoef q{};
+    if (COMPOSE) q = cw[r].q;                      // uniform address: scalar loads, the coefficients live in SGPRs
     auto G_at = [&](size_t p) -> float {          // dL/dIWE at pixel p of this (window, reference time)
         if (COMPOSE) return compose_G(q, gradmag, gradmag ? Gi[p] : 0.0f, Ei[p], Ii[p]);
         return Gi[p];
+    };
+    auto G_far = [&](size_t p) -> float {         // the same for the rare taps outside the LDS window, inside the event loop
+        if (!COMPOSE) return Gi[p];
+        return compose_G(q, gradmag, gradmag ? Gi[p] : 0.0f, Ei[p], Ii[p]);
     };
     if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {      // the usual case: window inside the image
         const size_t o0 = (size_t)wn.oy * g.W + wn.ox;
@@ -1539,11 +1571,10 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
     double gscale = 0.0;                          // 2^eg of this window's gradient accumulators
     if (!direct11) {
         double gm;
-        if (COMPOSE) {
-            gm = sbound[0];
-            for (int rr = 1; rr < g.R; ++rr) gm = fmax(gm, sbound[rr]);
-            gm = (double)(float)gm;               // the consumers of the accumulators (k_project, k_final*) read it back as a float
-            if (threadIdx.x == 0 && r == 0) gmax[it.win] = __float_as_uint((float)gm);      // every workgroup of the window writes the same bits
+        if (COMPOSE) {                            // the same R words k_project / k_final* read through gmax_of (gmax_n = R)
+            float gmf = cw[0].bound;
+            for (int rr = 1; rr < g.R; ++rr) gmf = fmaxf(gmf, cw[rr].bound);
+            gm = (double)gmf;
         } else {
             __shared__ unsigned gms[NTH / 64];
             gm = gmax_of(gmax + (size_t)it.win * g.gmax_n, g.gmax_n, gms);
@@ -1561,7 +1592,7 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         const int x = ev.xy & 0xffff, y = ev.xy >> 16;
         const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)];
         float gwx, gwy;
-        event_dLdw(g, wn, lds, G_at, x, y, v, dt, gwx, gwy);
+        event_dLdw(g, wn, lds, G_far, x, y, v, dt, gwx, gwy);
         if (direct11) {          // theta (1,1,2): Theta is constant, dL/dtheta = sum over all events; no per-pixel image needed.
             // fp32 over the thread's own <= 32 terms (their rounding errors are independent across 10^6 threads and average out:
             // measured 1e-9 relative on the gradient), fp64 from there on
