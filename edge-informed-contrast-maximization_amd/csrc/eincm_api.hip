@@ -55,8 +55,10 @@ struct eincm_ctx {
     std::vector<int64_t> win_events;
 
     // device buffers
-    uint32_t* d_xy = nullptr;      // (maxN) x | y<<16, binned
+    uint32_t* d_xy = nullptr;      // (maxN) x | y<<16, binned by (window, tile); the splat's copy: time order inside a tile, re-dealt in blocks of 256 (k_spread)
     double* d_t = nullptr;         // (maxN)
+    uint32_t* d_xy_g = nullptr;    // (maxN) the gather's copy: the same bins, every segment of d_items sorted by source pixel and dealt to its threads (k_segsort)
+    double* d_t_g = nullptr;       // (maxN)
     Item* d_items = nullptr;       // (max_items) segments walked by k_gather / k_count / k_mask
     Item* d_items_s = nullptr;     // (max_items) shorter segments walked by k_splat
     int32_t* d_order = nullptr;    // (max_items) d_items by decreasing length: the order the event kernels' workgroups take them in
@@ -66,10 +68,17 @@ struct eincm_ctx {
     Window* d_wins = nullptr;      // (max_items, maxR) destination windows of the gather segments under the current theta
     Window* d_wins_s = nullptr;    // (max_items, maxR) ... of the splat segments
     int n_items_s = 0; int seg_s = 0; int seg_s_used = 0;
+    // third list: the segments the 2-DoF gather walks, on the SPLAT's copy of the events (it has no per-pixel accumulators, so the
+    // time-ordered copy serves it, and it wants shorter segments than the theta-grid gather does: round-2 tuning)
+    Item* d_items_2 = nullptr; int32_t* d_order_2 = nullptr; int32_t* d_win_item0_2 = nullptr;
+    int n_items_2 = 0; int seg_2_used = 0;
+    std::vector<int32_t> h_order_2, h_win_item0_2;
+    int wincap_2 = WIN_CAP_DEFAULT;
     int wincap = WIN_CAP_DEFAULT;
     bool wincap_fixed = false;     // EINCM_WINCAP pins the capacity; otherwise it is chosen per evaluation from max|theta|
     bool chunk_fixed = false;      // EINCM_CHUNK given
     int g11_per_item = 1;          // slots per segment in d_g11 written by the last gather launch
+    double gather_wg_events = 4096.0;   // events a 2-DoF gather workgroup should take (set_windows: by batch size)
     // device-side staging (eincm_binning.hip.h)
     int16_t* d_raw_x = nullptr; int16_t* d_raw_y = nullptr; double* d_raw_t = nullptr;   // (maxN) events as handed over
     BinBlock* d_binblocks = nullptr; int32_t* d_win_blk = nullptr; uint32_t* d_blockhist = nullptr;
@@ -263,7 +272,7 @@ void multi_ref_weights(int R, double* w) {
 
 void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(c->d_xy); F(c->d_t); F(c->d_items); F(c->d_items_s); F(c->d_order); F(c->d_order_s); F(c->d_wins); F(c->d_wins_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
+    F(c->d_xy); F(c->d_t); F(c->d_xy_g); F(c->d_t_g); F(c->d_items); F(c->d_items_s); F(c->d_items_2); F(c->d_order_2); F(c->d_win_item0_2); F(c->d_order); F(c->d_order_s); F(c->d_wins); F(c->d_wins_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
     F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_itembase_s); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_acc); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
     F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax); F(c->d_cntmax); F(c->d_amax); F(c->d_gbound); F(c->d_ticket); F(c->d_coef); F(c->d_Gimg);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
@@ -371,6 +380,25 @@ void segment_lengths(const std::vector<int32_t>& tilecount, int seg, std::vector
     for (int32_t cnt : tilecount) {
         const int len = balanced_seg_len(cnt, seg);
         for (int s0 = 0; s0 < cnt; s0 += len) lens.push_back(std::min(len, cnt - s0));
+    }
+}
+
+// A segment list from the (window, tile) populations, the way k_items emits it (time ranges left to k_seg_minmax); win_item0: first
+// segment of every window.
+void host_items(const std::vector<int32_t>& tilecount, int ntiles, int seg, std::vector<Item>& items, std::vector<int32_t>& win_item0) {
+    items.clear(); win_item0.clear();
+    int64_t base = 0;
+    for (size_t idx = 0; idx < tilecount.size(); ++idx) {
+        if (idx % (size_t)ntiles == 0) win_item0.push_back((int32_t)items.size());
+        const int cnt = tilecount[idx];
+        const int len = balanced_seg_len(cnt, seg);
+        for (int s0 = 0; s0 < cnt; s0 += len) {
+            Item it;
+            it.win = (int32_t)(idx / (size_t)ntiles); it.tile = (int32_t)(idx % (size_t)ntiles);
+            it.begin = (int32_t)(base + s0); it.count = std::min(len, cnt - s0); it.t_lo = 0.0; it.t_hi = 0.0;
+            items.push_back(it);
+        }
+        base += cnt;
     }
 }
 
@@ -579,6 +607,12 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         cap_a = std::max(cap_a, cap);
         c->g.wincap_a = cap_a;
         c->g.winmaxw_a = std::max(40, (int)std::lround(std::sqrt((double)cap_a * 1.4)));
+        // and the 2-DoF gather's list
+        const double tspan_2 = std::min(1.0, (double)c->seg_2_used / std::max(per_tile, 1.0));
+        const double side_2 = TS + 4 + vmax * tspan_2;
+        int cap_2 = caps[3];
+        for (int k = 0; k < 4; ++k) if (side_2 * side_2 <= caps[k]) { cap_2 = caps[k]; break; }
+        c->wincap_2 = cap_2;
     }
     // 2-DoF theta with nothing but the contrast and correlation terms (every level above 0 of the reference's pyramid at its first
     // level, and the bench workload): the scalar assembly and the sum of the gather's per-workgroup partials run on the host
@@ -679,21 +713,37 @@ int eval_end_launch(eincm_ctx* c) {
                 // Theta grids / dense theta: the gather walks whichever segment list has the longer segments (its per-workgroup
                 // costs - Theta tile, accumulator clear and flush - want them long even for one window, where the 2-DoF gather
                 // wants 4096); nothing downstream depends on the list (the per-segment partials are a 2-DoF matter).
-                const bool use_s = !direct11 && c->seg_s_used > c->seg_used && c->n_items_s > 0;
-                const int n_g = use_s ? c->n_items_s : c->n_items;
-                const Item* items_g = use_s ? c->d_items_s : c->d_items;
-                const Window* wins_g = use_s ? c->d_wins_s : c->d_wins;
-                const int32_t* order_g = use_s ? c->d_order_s : c->d_order;
-#define GATHER_ARGS(NTH) dim3(use_s ? splat_grid(c) : event_grid(c)), dim3(NTH), \
-                    (use_s ? g.wincap : g.wincap_a) * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), \
-                    g, n_g, items_g, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, wins_g, c->d_gTheta, \
+                // Theta grids / dense theta: the gather walks its own segment list (long segments) on its own copy of the events
+                // (k_segsort); 2-DoF theta: its third list (shorter segments) on the splat's copy
+                const int n_g = direct11 ? c->n_items_2 : c->n_items;
+                const Item* items_g = direct11 ? c->d_items_2 : c->d_items;
+                const Window* wins_g = c->d_wins;                  // (2-DoF theta derives its windows itself)
+                const int32_t* order_g = direct11 ? c->d_order_2 : c->d_order;
+                const uint32_t* xy_g = direct11 ? c->d_xy : c->d_xy_g;
+                const double* t_g = direct11 ? c->d_t : c->d_t_g;
+                Geom gg = g;
+                if (direct11) { gg.wincap_a = c->wincap_2; gg.winmaxw_a = std::max(40, (int)std::lround(std::sqrt((double)c->wincap_2 * 1.4))); }
+                const unsigned grid_g = (unsigned)(((n_g + NXCD - 1) / NXCD) * NXCD * g.R);
+                // 2-DoF theta: workgroups per segment, so that a workgroup takes about what the round-2 tuning found best for this
+                // kernel (4096 events on one window, 16384 on the 8-window batch) whatever the segment length of the list
+                int nparts = 1;
+                if (direct11) {
+                    const double per_tile = (double)std::max<int64_t>(c->n_events, 1) / ((double)g.B * g.ntiles);
+                    const double seg_eff = std::min((double)c->seg_2_used, per_tile);
+                    const double target = c->gather_wg_events;
+                    nparts = seg_eff >= 3.0 * target ? 4 : (seg_eff >= 1.5 * target ? 2 : 1);
+                    if (const char* e = getenv("EINCM_GATHER_PARTS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nparts = v; }
+                }
+#define GATHER_ARGS(NTH) dim3(grid_g, nparts), dim3(NTH), \
+                    gg.wincap_a * sizeof(float) + (direct11 ? 0 : TS * TS * 2 * sizeof(double) + TS * TS * sizeof(double2)), \
+                    gg, n_g, items_g, xy_g, t_g, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, wins_g, c->d_gTheta, \
                     direct11 ? 1 : 0, host_asm ? c->h_g11 : c->d_g11, c->d_wc, gmax_buf, direct11 ? THETA_CONST : THETA_TILE, order_g, \
                     c->pend.use_arg ? 1 : 0, c->pend.theta_dev, c->pend.targ, \
-                    ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG ? 1 : 0, c->d_edges, c->d_iwe, c->d_coef, c->d_acc, use_s ? 0 : 1
+                    ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG ? 1 : 0, c->d_edges, c->d_iwe, c->d_coef, c->d_acc, 1, nparts
                 if (direct11) {
                     if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 1>, GATHER_ARGS(NT));
                     else         launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 0>, GATHER_ARGS(NT));
-                    c->g11_per_item = g.R;
+                    c->g11_per_item = g.R * nparts;
                 } else if (wide) {
                     if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 1, NT_TILE, 1>, GATHER_ARGS(NT_TILE));
                     else         launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 1, NT_TILE, 0>, GATHER_ARGS(NT_TILE));
@@ -719,7 +769,7 @@ int eval_end_launch(eincm_ctx* c) {
         // small results (everything but a dense gradient) are written by k_final straight into pinned host memory: no D2H copy command
         launch_timed(c, EINCM_STAGE_FINAL, k_final, dim3(g.B), dim3(FT), 0, g, ep, c->d_parts, c->d_divparts, c->d_tvparts,
                            c->d_tmm, c->d_wc, g2_from_imgrad ? c->d_g2parts : nullptr, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap,
-                           c->d_g11, c->d_win_item0, c->n_items, c->g11_per_item, gmax_buf,
+                           c->d_g11, c->d_win_item0_2, c->n_items_2, c->g11_per_item, gmax_buf,
                            zero_copy_out ? c->h_outs : c->d_outs, zero_copy_out ? c->h_grad : c->d_grad, want_grad ? 1 : 0);
         if (want_grad && identity) {
             hipLaunchKernelGGL(k_final_dense, dim3(256, g.B), dim3(NT), 0, c->stream, g, ep.use_tv_grad, wide ? 1 : 0, c->d_gTheta,
@@ -802,9 +852,9 @@ void host_assemble(eincm_ctx* c) {
         o.tv = (ep.cur_pyr_lvl <= 0) ? NAN : 0.0;
         o.value = val; o.tv_scale = 0.0;
         o.nonfinite = std::isfinite(val) ? 0.0 : 1.0;
-        const int lo = c->h_win_item0[b], hi = (b + 1 < g.B) ? c->h_win_item0[b + 1] : c->n_items;
-        const double* p = c->h_g11 + (size_t)lo * g.R * 2;
-        const size_t n = (size_t)(hi - lo) * g.R;
+        const int lo = c->h_win_item0_2[b], hi = c->h_win_item0_2[b + 1];
+        const double* p = c->h_g11 + (size_t)lo * c->g11_per_item * 2;
+        const size_t n = (size_t)(hi - lo) * c->g11_per_item;
         double sx = 0.0, sy = 0.0;
         for (size_t k = 0; k < n; ++k) { sx += p[2 * k]; sy += p[2 * k + 1]; }
         c->h_grad[(size_t)b * 2] = sx; c->h_grad[(size_t)b * 2 + 1] = sy;
@@ -998,10 +1048,15 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     c->coarse_cap = 64 * 64 * 2;   // coarse theta up to 64x64 (the pyramid tops out at 16x16); grown on demand
     TRY(dalloc(&c->d_xy, (size_t)max_events_total));
     TRY(dalloc(&c->d_t, (size_t)max_events_total));
+    TRY(dalloc(&c->d_xy_g, (size_t)max_events_total));
+    TRY(dalloc(&c->d_t_g, (size_t)max_events_total));
     TRY(dalloc(&c->d_items, (size_t)c->max_items));
     TRY(dalloc(&c->d_items_s, (size_t)c->max_items));
     TRY(dalloc(&c->d_order, (size_t)c->max_items));
     TRY(dalloc(&c->d_order_s, (size_t)c->max_items));
+    TRY(dalloc(&c->d_items_2, (size_t)c->max_items));
+    TRY(dalloc(&c->d_order_2, (size_t)c->max_items));
+    TRY(dalloc(&c->d_win_item0_2, B + 1));
     TRY(dalloc(&c->d_wins, (size_t)c->max_items * max_refs));
     TRY(dalloc(&c->d_wins_s, (size_t)c->max_items * max_refs));
     c->host_binning = (ntiles > BIN_MAX_TILES) || (getenv("EINCM_HOST_BINNING") != nullptr);
@@ -1027,7 +1082,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(hipMemset(c->d_acc, 0, B * R * img * sizeof(unsigned long long)));
     TRY(dalloc(&c->d_iwe, B * R * img));
     TRY(dalloc(&c->d_G, B * R * img));
-    TRY(dalloc(&c->d_g11, (size_t)(c->max_items + NXCD) * R * 2));
+    TRY(dalloc(&c->d_g11, (size_t)(c->max_items + NXCD) * R * 2 * 4));      // x4: up to four workgroups share a segment
     TRY(dalloc(&c->d_win_item0, B + 1));
     TRY(dalloc(&c->d_dtmax, B));
     TRY(dalloc(&c->d_cntmax, B));
@@ -1070,7 +1125,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_coltap, (size_t)W));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_theta), B * img * 2 * sizeof(double), hipHostMallocDefault));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_wc), B * sizeof(WinConst), hipHostMallocDefault));
-    TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_g11), (size_t)(c->max_items + NXCD) * R * 2 * sizeof(double), hipHostMallocDefault));
+    TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_g11), (size_t)(c->max_items + NXCD) * R * 2 * 4 * sizeof(double), hipHostMallocDefault));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_g2), B * R * nig * sizeof(double), hipHostMallocDefault));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_img), B * R * IMGSCAL_N * sizeof(double), hipHostMallocDefault));
     c->have_events = true;
@@ -1126,7 +1181,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     g.pstride = std::max(std::max(g.ntiles, NSPART), (g.nig + IG_NT / 64 - 1) / (IG_NT / 64));
     g.gmax_n = g.R * g.nig;
     g.wincap = c->wincap; g.winmaxw = std::max(40, (int)std::lround(std::sqrt((double)c->wincap * 1.4)));
-    g.wincap_a = g.wincap; g.winmaxw_a = g.winmaxw;
+    g.wincap_a = g.wincap; g.winmaxw_a = g.winmaxw; c->wincap_2 = g.wincap;
 
     // Segment lengths (events per workgroup and reference time), measured on MI355X with the longest-first order of block_to_work
     // (tools/dev_tune_seg.py, profiles/r02/segment_tuning.txt).  Per-workgroup fixed cost (window clear / flush, G-window load,
@@ -1139,10 +1194,17 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     //   theta grids / dense theta: the gather walks the list with the longer segments (one 10^6-event window at 16x16: 35.8 us
     //             with 4096, 30.3 with 8192, 28.6 with 16384; the 8-window batch 157 / 144 / 139 with 8192 / 16384 / 32768).
     const double x_wg = ((double)N / 8192.0 + 0.5 * n_windows * g.ntiles) * n_refs;
-    int seg = c->seg > 0 ? c->seg : (x_wg >= 4000.0 ? 16384 : (x_wg < 1000.0 ? 4096 : 8192));
+    // Round 3: the gather's list always has long segments (what its theta-grid form wants: thtile, accumulator clear and flush per
+    // workgroup); its 2-DoF form shares a segment among up to four workgroups instead (gather_wg_events, k_gather's nparts).
+    int seg = c->seg > 0 ? c->seg : 16384;
+    c->gather_wg_events = 1e30;              // (k_gather's nparts: an experiment, EINCM_GATHER_PARTS)
+    int seg_2 = x_wg >= 4000.0 ? 16384 : (x_wg < 1000.0 ? 4096 : 8192);       // the 2-DoF gather's own list (round-2 tuning)
+    if (const char* e = getenv("EINCM_SEG_2DOF")) { const int v = atoi(e); if (v >= 64 && v <= MAX_SEG) seg_2 = v; }
+    c->seg_2_used = seg_2;
     c->seg_used = seg;
     int seg_s = c->seg_s > 0 ? c->seg_s : (x_wg >= 400.0 ? 8192 : 4096);     // one window at R = 1: 4096 (0.066 vs 0.075 ms per evaluation)
     c->seg_s_used = seg_s;
+    const bool sort_segments = getenv("EINCM_NO_SEGSORT") == nullptr;
     if (!c->chunk_fixed) c->chunk = std::max(4096, std::min(seg_s, MAX_CHUNK));     // single-chunk segments: no f32 commit pass
     const size_t img = (size_t)H * W;
     for (int b = 0; b < n_windows; ++b) {
@@ -1234,11 +1296,21 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         if (nblk > 0) {
             hipLaunchKernelGGL(k_bin_scatter, dim3(nblk), dim3(BIN_NT), g.ntiles * sizeof(uint32_t), c->stream, g, c->d_binblocks, c->d_raw_x, c->d_raw_y,
                                c->d_raw_t, c->d_blockhist, c->d_tilebase, c->d_xy, c->d_t);
+            hipLaunchKernelGGL(k_items, dim3((M + 255) / 256), dim3(256), 0, c->stream, g, seg, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_items);
+            if (n_items_total > 0) {
+                // the gather's copy: every segment of its list sorted by source pixel and dealt to the threads that walk it (from the
+                // binned time order, before the splat's copy is re-dealt in place)
+                if (sort_segments)
+                    hipLaunchKernelGGL(k_segsort, dim3(std::min(n_items_total, 8192)), dim3(SORT_NT), 0, c->stream, n_items_total, c->d_items,
+                                       c->d_xy, c->d_t, c->d_xy_g, c->d_t_g);
+                else {
+                    HIPCHK(c, hipMemcpyAsync(c->d_xy_g, c->d_xy, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+                    HIPCHK(c, hipMemcpyAsync(c->d_t_g, c->d_t, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                }
+                hipLaunchKernelGGL(k_seg_minmax, dim3(std::min(n_items_total, 4096)), dim3(NT), 0, c->stream, n_items_total, c->d_items, c->d_t_g);
+            }
             if (!getenv("EINCM_NO_SPREAD"))
                 hipLaunchKernelGGL(k_spread, dim3(M, SPREAD_Y), dim3(256), 0, c->stream, g, c->d_tilecount, c->d_tilebase, c->d_xy, c->d_t);
-            hipLaunchKernelGGL(k_items, dim3((M + 255) / 256), dim3(256), 0, c->stream, g, seg, c->d_tilecount, c->d_tilebase, c->d_itembase, c->d_items);
-            if (n_items_total > 0)
-                hipLaunchKernelGGL(k_seg_minmax, dim3(std::min(n_items_total, 4096)), dim3(NT), 0, c->stream, n_items_total, c->d_items, c->d_t);
             // per window: first segment and max |t - tau| (needs the segment time ranges and the FIRST segmentation's itembase)
             HIPCHK(c, hipMemcpyAsync(c->d_edge_ts, edge_ts, (size_t)n_windows * n_refs * sizeof(double), hipMemcpyHostToDevice, c->stream));
             hipLaunchKernelGGL(k_win_consts, dim3(n_windows), dim3(NT), 0, c->stream, g, n_items_total, c->d_items, c->d_itembase, c->d_edge_ts,
@@ -1273,6 +1345,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         }
     } else {
     // ---- host path (sensors with more tiles than the LDS histogram holds, or EINCM_HOST_BINNING=1): stable counting sort ----
+    c->h_tilecount.assign((size_t)n_windows * g.ntiles, 0);
     std::vector<uint32_t> sxy((size_t)std::max<int64_t>(N, 1));
     std::vector<double> st((size_t)std::max<int64_t>(N, 1));
     std::vector<Item> items, items_s;
@@ -1295,6 +1368,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             std::vector<uint32_t> pc((size_t)H * W, 0u);
             for (int64_t i = 0; i < n; ++i) cntmax_h[b] = std::max(cntmax_h[b], ++pc[(size_t)y[i] * W + x[i]]);
         }
+        for (int k = 0; k < g.ntiles; ++k) c->h_tilecount[(size_t)b * g.ntiles + k] = (int32_t)cnt[k + 1];
         for (int k = 0; k < g.ntiles; ++k) cnt[k + 1] += cnt[k];
         std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
         for (int64_t i = 0; i < n; ++i) {
@@ -1340,8 +1414,16 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
         HIPCHK(c, hipMemcpyAsync(c->d_xy, sxy.data(), (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_t, st.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
-    if (!items.empty())
+    if (!items.empty()) {
         HIPCHK(c, hipMemcpyAsync(c->d_items, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
+        if (sort_segments)      // the gather's copy; a permutation inside the segments: their time ranges (computed above) are unchanged
+            hipLaunchKernelGGL(k_segsort, dim3((unsigned)std::min<size_t>(items.size(), 8192)), dim3(SORT_NT), 0, c->stream, (int)items.size(), c->d_items,
+                               c->d_xy, c->d_t, c->d_xy_g, c->d_t_g);
+        else {
+            HIPCHK(c, hipMemcpyAsync(c->d_xy_g, c->d_xy, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_t_g, c->d_t, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
     if (!items_s.empty())
         HIPCHK(c, hipMemcpyAsync(c->d_items_s, items_s.data(), items_s.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
     {
@@ -1363,7 +1445,23 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     }
     HIPCHK(c, hipMemcpyAsync(c->d_edge_ts, edge_ts, (size_t)n_windows * n_refs * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_mask, 0, (size_t)n_windows * img, c->stream));
+    std::vector<Item> items_2;
+    {   // the 2-DoF gather's segment list (splat copy of the events): generated on the host from the tile populations
+        host_items(c->h_tilecount, g.ntiles, seg_2, items_2, c->h_win_item0_2);
+        if ((int64_t)items_2.size() > c->max_items) return fail(c, EINCM_ERR_ARG, "internal: %zu segments exceed capacity", items_2.size());
+        c->h_win_item0_2.resize((size_t)n_windows + 1, (int32_t)items_2.size());
+        std::vector<int32_t> lens(items_2.size());
+        for (size_t i = 0; i < items_2.size(); ++i) lens[i] = items_2[i].count;
+        order_by_length(lens, c->h_order_2);
+        if (!items_2.empty()) {
+            HIPCHK(c, hipMemcpyAsync(c->d_items_2, items_2.data(), items_2.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_order_2, c->h_order_2.data(), c->h_order_2.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_seg_minmax, dim3((unsigned)std::min<size_t>(items_2.size(), 4096)), dim3(NT), 0, c->stream, (int)items_2.size(), c->d_items_2, c->d_t);
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_win_item0_2, c->h_win_item0_2.data(), (size_t)(n_windows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n_items_2 = (int)items_2.size();
     c->g = g; c->n_items = n_items_total; c->n_items_s = n_items_s_total; c->n_events = N;
     c->itembase_valid = !c->host_binning && n_items_total > 0 && n_items_s_total > 0;      // both tile scans ran on the device
     c->win_events.assign(n_events, n_events + n_windows);

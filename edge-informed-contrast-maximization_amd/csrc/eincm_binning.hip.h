@@ -7,10 +7,11 @@
 //   k_bin_tilescan one workgroup: exclusive scans of tile counts and of segment counts    -> tilebase, itembase, n_items
 //   k_bin_scatter  per block: position = tilebase + blockoff + LDS rank                   -> ev_xy, ev_t (binned)
 //   k_items / k_seg_minmax                                                                -> segments with their time range
+//   k_segsort                                                                             -> the order inside a segment (see there)
 // The sort is STABLE: a block is one wave walking its 1024 events in input order, and events of a wave-step that share a tile are
-// ranked by lane (k_bin_scatter), so a tile's events keep the order they were handed over in, and staging the same window twice
-// gives the same binned arrays bit for bit.  The fp64 per-thread sums of k_gather (2-DoF theta) depend on that order, so this is
-// what makes a re-staged window reproduce its gradient exactly.
+// ranked by lane (k_bin_scatter), so a tile's events keep the order they were handed over in; k_segsort is a stable sort of a
+// segment's events by source pixel.  Staging the same window twice therefore gives the same arrays bit for bit.  The per-thread sums
+// of k_gather depend on that order, so this is what makes a re-staged window reproduce its gradient exactly.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -169,6 +170,109 @@ __global__ __launch_bounds__(256) void k_spread(Geom g, const int32_t* __restric
         const int pos = (rank & 3) * 64 + (rank >> 2);
         ev_xy[base + b0 + pos] = xy;                      // every thread has read its event: the block-local permutation is safe in place
         ev_t[base + b0 + pos] = tm;
+    }
+}
+
+// k_segsort: the order of the events INSIDE a segment of the GATHER's copy of the events (round 3).  The two event kernels want
+// different orders, so staging keeps two copies (12 B per event each): the splat's (time order inside a tile, re-dealt in blocks of
+// 256: k_spread above - a wavefront holds events of nearly one time, so distinct source pixels go to distinct destination pixels) and
+// this one.  A segment's events are sorted by source pixel (stable: input = time order), and the sorted sequence is dealt to the threads that
+// will walk it so that a THREAD owns a contiguous run of it (SegWalk in eincm_kernels.hip.h): the segment is cut in two halves,
+// a half of nc events is walked by 256 threads in K = ceil(nc / 256) coalesced steps, thread t taking sorted events
+// [start_t, start_t + K or K - 1), event j of thread t stored at  half_base + j * 256 + t.  Consequences:
+//   * consecutive events of a thread mostly share their source pixel: the theta-grid gather adds a RUN of -dt dL/dw in registers and
+//     issues one pair of LDS atomics per run instead of per event, and re-reads the pixel's velocity only when the pixel changes;
+//     the splat can merge the taps of consecutive events that round to the same destination;
+//   The splat must NOT walk this order: its lanes would hold events of different times, and near the optimum events of one scene
+//   point - different pixels at different times - warp onto one destination pixel (that is what contrast maximisation does), so a
+//   wavefront's LDS atomics collide: k_splat 94 -> 123 us on the bench batch, 108 -> 172 us at 16x16 theta (profiles/r03/layout_experiments.md).
+// The permutation is a function of the segment's content alone (stable counting sort, lanes ranked in lane order), so re-staging
+// reproduces the arrays bit for bit.  Any order inside a segment is CORRECT (integer accumulation; the kernels walk every slot);
+// this one is fast.  One workgroup of 4 waves per segment: each wave owns a quarter of the input (contiguous, in input order),
+// counts its keys, and after the scan over (key, wave) places its quarter in order.
+struct SegLayout {                 // where the sorted event of rank s (0 <= s < n) of a segment is stored, relative to the segment
+    int n0, K0, K1, rem0, rem1;
+    __host__ __device__ explicit SegLayout(int n) {
+        n0 = (n + 1) >> 1;
+        const int n1 = n - n0;
+        K0 = (n0 + 255) >> 8; K1 = (n1 + 255) >> 8;
+        rem0 = n0 - 256 * (K0 - 1); rem1 = n1 - 256 * (K1 - 1);           // entries of the last step of each half (1..256; unused when K == 0)
+    }
+    __host__ __device__ int position(int s) const {
+        const int c = s >= n0;
+        const int sc = c ? s - n0 : s, K = c ? K1 : K0, rem = c ? rem1 : rem0;
+        int t, j;
+        if (sc < rem * K) { t = sc / K; j = sc - t * K; }
+        else { const int q = sc - rem * K; t = rem + q / (K - 1); j = q - (t - rem) * (K - 1); }
+        return (c ? n0 : 0) + j * 256 + t;
+    }
+};
+constexpr int SORT_NT = 256, SORT_NW = SORT_NT / 64, SORT_KEYS = TS * TS;
+__device__ __forceinline__ uint32_t pixkey(uint32_t xy) { return ((xy >> 11) & (31u << 5)) | (xy & 31u); }     // pixel inside the 32x32 tile (raster order)
+__global__ __launch_bounds__(SORT_NT) void k_segsort(int n_items, const Item* __restrict__ items,
+                                                      const uint32_t* __restrict__ src_xy, const double* __restrict__ src_t,
+                                                      uint32_t* __restrict__ dst_xy, double* __restrict__ dst_t)
+{
+    __shared__ uint32_t cnt[SORT_NW][SORT_KEYS];        // per (wave, key): count, then the running output rank
+    __shared__ uint32_t wsum[SORT_NT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int k = blockIdx.x; k < n_items; k += gridDim.x) {
+        const Item it = items[k];
+        const int n = it.count, begin = it.begin;
+        const int qlen = (((n + SORT_NW - 1) / SORT_NW + 63) / 64) * 64;           // a wave's share of the input: whole wave steps
+        const int lo = min(wv * qlen, n), hi = min(lo + qlen, n);
+        for (int i = threadIdx.x; i < SORT_NW * SORT_KEYS; i += SORT_NT) (&cnt[0][0])[i] = 0u;
+        __syncthreads();
+        for (int i = lo + lane; i < hi; i += 64) atomicAdd(&cnt[wv][pixkey(src_xy[begin + i])], 1u);
+        __syncthreads();
+        // exclusive scan over (key, wave), key-major: thread t owns keys 4t .. 4t+3
+        uint32_t c[4][SORT_NW], tot = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int w = 0; w < SORT_NW; ++w) { c[q][w] = cnt[w][4 * threadIdx.x + q]; tot += c[q][w]; }
+        wsum[threadIdx.x] = tot;
+        __syncthreads();
+        for (int off = 1; off < SORT_NT; off <<= 1) {          // Hillis-Steele inclusive scan of the 256 thread totals
+            const uint32_t v = (threadIdx.x >= off) ? wsum[threadIdx.x - off] : 0u;
+            __syncthreads();
+            wsum[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = wsum[threadIdx.x] - tot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int w = 0; w < SORT_NW; ++w) { cnt[w][4 * threadIdx.x + q] = run; run += c[q][w]; }
+        __syncthreads();
+        // placement: a wave walks its quarter in input order; lanes of a step that share a key are ranked by lane
+        const SegLayout L(n);
+        for (int i0 = lo; i0 < hi; i0 += 64) {                  // wave-uniform trip count
+            const int i = i0 + lane;
+            const bool valid = i < hi;
+            uint32_t xy = 0u; double t = 0.0; int key = -1;
+            if (valid) { xy = src_xy[begin + i]; t = src_t[begin + i]; key = (int)pixkey(xy); }
+            unsigned long long todo = __ballot(valid);
+            uint32_t rank = 0u;
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int Kk = __shfl(key, leader, 64);
+                const unsigned long long grp = __ballot(key == Kk);
+                const uint32_t base = cnt[wv][Kk];                  // every lane reads the same word before the leader updates it
+                if (key == Kk) rank = base + (uint32_t)__popcll(grp & lt_mask);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == leader) cnt[wv][Kk] = base + (uint32_t)__popcll(grp);
+                __builtin_amdgcn_wave_barrier();
+                todo &= ~grp;
+            }
+            if (valid) {
+                const int pos = L.position((int)rank);
+                dst_xy[begin + pos] = xy;
+                dst_t[begin + pos] = t;
+            }
+        }
+        __syncthreads();                                        // cnt is reused by the next segment of this workgroup
     }
 }
 

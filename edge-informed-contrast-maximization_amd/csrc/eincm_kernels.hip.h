@@ -576,6 +576,31 @@ template <int NTH> struct WinWalkT {
 };
 using WinWalk = WinWalkT<NT>;
 
+// How the threads of a k_gather workgroup walk a segment of n events in the layout staging gives the gather's copy (k_segsort,
+// eincm_binning.hip.h): two halves of n0 = ceil(n / 2) and n - n0 events, each stored as K coalesced steps of 256 threads, the
+// last step a prefix.  A 512-thread workgroup gives each half to 256 of its threads (K0 uniform iterations); a 256-thread
+// workgroup walks the halves one after the other (K0 + K1 iterations).  index() < 0: this thread has no event in iteration i.
+// Consecutive events of a thread are consecutive in the segment's sort by source pixel.
+template <int NTH> struct SegWalk {
+    static_assert(NTH == 256 || NTH == 512, "the staged layout is dealt to groups of 256 threads");
+    int n0, K0, K1, rem0, rem1, tt, half;
+    __device__ __forceinline__ SegWalk(int n, int tid) {
+        n0 = (n + 1) >> 1;
+        const int n1 = n - n0;
+        K0 = (n0 + 255) >> 8; K1 = (n1 + 255) >> 8;
+        rem0 = n0 - 256 * (K0 - 1); rem1 = n1 - 256 * (K1 - 1);
+        tt = tid & 255; half = tid >> 8;
+    }
+    __device__ __forceinline__ int iters() const { return NTH == 512 ? K0 : K0 + K1; }
+    __device__ __forceinline__ int index(int i) const {
+        const int c = (NTH == 512) ? half : (i >= K0 ? 1 : 0);
+        const int j = (NTH == 512) ? i : (c ? i - K0 : i);
+        const int K = c ? K1 : K0, rem = c ? rem1 : rem0;
+        const bool ok = j < K - 1 || (j == K - 1 && tt < rem);
+        return ok ? (c ? n0 : 0) + j * 256 + tt : -1;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // k_splat: the dominant kernel.  grid ceil(n_items/8)*8*R blocks (block_to_work), LDS 2*WIN_CAP*4 bytes.
 // A segment is walked in chunks of <= chunk events; each chunk is accumulated in u32 fixed point (exact integer
@@ -635,15 +660,14 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
     const int n = it.count;
     const int iters = (n + NTH - 1) / NTH;            // uniform over the workgroup
     const int ipc = chunk / NTH;                     // iterations per chunk (chunk is a multiple of NTH)
-    int fshift = fix_shift(min(chunk, n));
-    float FIX_SCALE = ldexpf(1.0f, fshift), FIX_INV = ldexpf(1.0f, -fshift);
+    const int fshift = fix_shift(min(chunk, n));
+    const float FIX_SCALE = ldexpf(1.0f, fshift), FIX_INV = ldexpf(1.0f, -fshift);
 
     // Software pipeline over the segment's events, unrolled x3 with renamed register sets (no rotation moves, so no forced
     // vmcnt(0)): the (xy, t) loads of event j+2 are in flight while event j is splatted.
     const int tid = threadIdx.x;
     auto load_ev = [&](EvReg& r, int e) { if (e < n) { r.xy = exy[e]; r.t = et[e]; } else { r.xy = 0u; r.t = 0.0; } };
-    const float scale_y = INV_2PI * FIX_SCALE;      // single-chunk segments: constant over the loop (re-derived after a commit)
-    float scy = scale_y;
+    const float scy = INV_2PI * FIX_SCALE;          // one fixed-point scale per segment: every chunk holds <= min(chunk, n) events
     auto splat_ev = [&](const EvReg& ev) {
         const double dt = ev.t - tau;
         const int x = ev.xy & 0xffff, y = ev.xy >> 16;
@@ -694,9 +718,6 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
                 if (u != 0u) { ldsf[i] += (float)u * FIX_INV; ldsu[i] = 0u; }
             }
             __syncthreads();
-            fshift = fix_shift(min(chunk, n - (j + 1) * NTH));
-            FIX_SCALE = ldexpf(1.0f, fshift); FIX_INV = ldexpf(1.0f, -fshift);
-            scy = INV_2PI * FIX_SCALE;
         }
     };
     EvReg A, B, C;
@@ -1498,8 +1519,10 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         int gradmag_i, const float* __restrict__ edges, const float* __restrict__ iwe,
         const ImgCoef* __restrict__ coef,      // (B,R) per-image scalars and |G| bounds from k_imstat's tail
         unsigned long long* __restrict__ acc,  // the u64 IWE accumulator: consumed by k_imstat, cleared here (a slice per workgroup)
-        int list_a)                            // the segments walked are the gather's own list (window capacity wincap_a), not the splat's
+        int list_a,                            // the segments walked are the gather's own list (window capacity wincap_a), not the splat's
+        int nparts)                            // 1, 2 or 4 = gridDim.y: workgroups sharing a segment (256-thread form only)
 {
+    const int part = blockIdx.y;
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
     if (TM != 0) direct11 = (TM == THETA_CONST) ? 1 : 0;     // the host ties the two (2-DoF theta <=> per-workgroup partials)
     const int wincap = list_a ? g.wincap_a : g.wincap, winmaxw = list_a ? g.winmaxw_a : g.winmaxw;
@@ -1513,7 +1536,8 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         // consumer-clears, delegated: k_imstat has read the accumulator (halos included), so every workgroup of this launch zeroes
         // an equal share of it with plain stores (fire and forget; nothing in this kernel reads it)
         const size_t total = (size_t)g.B * g.R * g.H * g.W;
-        const size_t lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
+        const size_t nb = (size_t)gridDim.x * gridDim.y, bid = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        const size_t lo = total * bid / nb, hi = total * (bid + 1) / nb;
         for (size_t i = lo + threadIdx.x; i < hi; i += NTH) acc[i] = 0ull;
     }
     int item, r;
@@ -1587,43 +1611,84 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
     const double* __restrict__ et = ev_t + it.begin;
     const int n = it.count;
     const int tid = threadIdx.x;
+    // Run state of a theta-grid / dense gather: consecutive events of a thread mostly share their source pixel (k_segsort), so
+    // -dt dL/dw is summed in fp64 registers over a run and enters the pixel's i64 accumulator once per run (two ds_add_u64 per
+    // RUN instead of per event: those atomics were what bound the round-2 kernel), and the pixel's velocity is read once per run.
+    uint32_t cur_key = 0xffffffffu;
+    double run_x = 0.0, run_y = 0.0;
+    double2 vcur = vconst;
+    auto flush_run = [&]() {
+        if (cur_key == 0xffffffffu) return;
+        unsigned long long* a = accum + (cur_key << 1);
+        atomicAdd(a, (unsigned long long)(WIDE ? fix64_wide(run_x) : fix64(run_x)));
+        atomicAdd(a + 1, (unsigned long long)(WIDE ? fix64_wide(run_y) : fix64(run_y)));
+    };
     auto gather_ev = [&](const EvReg& ev) {
         const double dt = ev.t - tau;
         const int x = ev.xy & 0xffff, y = ev.xy >> 16;
-        const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)];
+        if (theta_mode != THETA_CONST) {
+            const uint32_t key = ((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u);
+#ifdef EINCM_ABL_G_NORUN
+            vcur = thtile[key];
+#else
+            if (key != cur_key) {
+                flush_run();
+                cur_key = key; run_x = 0.0; run_y = 0.0;
+                vcur = thtile[key];
+            }
+#endif
+        }
         float gwx, gwy;
-        event_dLdw(g, wn, lds, G_far, x, y, v, dt, gwx, gwy);
+        event_dLdw(g, wn, lds, G_far, x, y, vcur, dt, gwx, gwy);
         if (direct11) {          // theta (1,1,2): Theta is constant, dL/dtheta = sum over all events; no per-pixel image needed.
-            // fp32 over the thread's own <= 32 terms (their rounding errors are independent across 10^6 threads and average out:
+            // fp32 over the thread's own <= 64 terms (their rounding errors are independent across 10^6 threads and average out:
             // measured 1e-9 relative on the gradient), fp64 from there on
             const float ndt = (float)(-dt);
             f11x = fmaf(ndt, gwx, f11x); f11y = fmaf(ndt, gwy, f11y);
         } else {
-            unsigned long long* a = accum + ((((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)) << 1);
             const double sdt = -dt * gscale;
-            atomicAdd(a, (unsigned long long)(WIDE ? fix64_wide(sdt * (double)gwx) : fix64(sdt * (double)gwx)));
-            atomicAdd(a + 1, (unsigned long long)(WIDE ? fix64_wide(sdt * (double)gwy) : fix64(sdt * (double)gwy)));
+            run_x = fma(sdt, (double)gwx, run_x); run_y = fma(sdt, (double)gwy, run_y);
         }
     };
-    // a plain strided loop: with 8 waves per SIMD the loads are hidden by occupancy; the renamed-register pipeline of
-    // k_splat measured 2.5 % slower here (133 vs 130 us)
-#ifndef EINCM_ABL_G_NOEVENTS
+    // the staged layout (SegWalk): a half of the segment is K coalesced steps of 256 threads, the last one a prefix
+    const SegWalk<NTH> walk(n, tid);
+    auto walk_half = [&](int c, int sub, int nsub) {      // steps [K sub / nsub, K (sub + 1) / nsub) of half c
+        const int K = c ? walk.K1 : walk.K0, rem = c ? walk.rem1 : walk.rem0;
+        const int j0 = K * sub / nsub, j1 = K * (sub + 1) / nsub;
+        const uint32_t* __restrict__ px = exy + (c ? walk.n0 : 0) + walk.tt;
+        const double* __restrict__ pt = et + (c ? walk.n0 : 0) + walk.tt;
+        const int jfull = min(j1, K - 1);
 #pragma unroll 2
-    for (int e = tid; e < n; e += NTH) {
-        EvReg ev; ev.xy = exy[e]; ev.t = et[e];
-        gather_ev(ev);
-    }
+        for (int j = j0; j < jfull; ++j) {
+            EvReg ev; ev.xy = px[j * 256]; ev.t = pt[j * 256];
+            gather_ev(ev);
+        }
+        if (j1 == K && K > 0 && j0 < K && walk.tt < rem) {
+            EvReg ev; ev.xy = px[(K - 1) * 256]; ev.t = pt[(K - 1) * 256];
+            gather_ev(ev);
+        }
+    };
+#ifndef EINCM_ABL_G_NOEVENTS
+    // nparts > 1 (2-DoF theta, few windows): a segment is shared by nparts workgroups (blockIdx.y), so that the segments can be long
+    // (what the theta-grid gather wants from the one list both walk) and the chip still sees enough workgroups
+    if (NTH == 512) walk_half(walk.half, 0, 1);
+    else if (nparts == 1) { walk_half(0, 0, 1); walk_half(1, 0, 1); }
+    else { const int nsub = nparts >> 1; walk_half(part / nsub, part % nsub, nsub); }
+    if (!direct11) flush_run();
 #endif
     if (direct11) {
         double sum11x = block_sum<NTH / 64>((double)f11x, red11);
         double sum11y = block_sum<NTH / 64>((double)f11y, red11);
         if (threadIdx.x == 0) {          // own slot, plain store, written unconditionally: nothing to clear, nothing to order
-            double* dst = g11 + ((size_t)item * g.R + r) * 2;
+            double* dst = g11 + (((size_t)item * nparts + part) * g.R + r) * 2;
             dst[0] = sum11x; dst[1] = sum11y;
         }
         return;
     }
     __syncthreads();
+#ifdef EINCM_ABL_G_NOFLUSH
+    return;
+#endif
     unsigned long long* __restrict__ gT = reinterpret_cast<unsigned long long*>(gTheta) + (size_t)it.win * g.H * g.W * 2;
     const int tw = min(TS, g.W - x0), th = min(TS, g.H - y0);
     for (int i = threadIdx.x; i < TS * TS * 2; i += NTH) {

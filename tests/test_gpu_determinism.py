@@ -77,9 +77,10 @@ def test_scipy_bfgs_solves_are_identical(built_lib):
 
 
 def test_event_order_inside_a_tile_only_moves_roundings(built_lib, monkeypatch):
-    """Staging re-deals the events of every 256-event block of a tile over the block's four wavefront groups (k_spread, for the LDS atomic
-    unit's sake).  Integer accumulation makes the images independent of the order of the events: the IWE and the count images are
-    bit-identical with and without the re-deal, the loss therefore too; only the gradient's per-thread partial sums may round differently."""
+    """Staging sorts the events of every segment by source pixel and deals the sorted sequence to the threads that walk it (k_segsort: runs of
+    one pixel per thread, different pixels across a wavefront).  Integer accumulation makes the images independent of the order of the events:
+    the IWE and the count images are bit-identical with and without the sort, the loss therefore too; only the gradient's per-thread sums
+    (2-DoF) and per-run sums (theta grids) may round differently."""
     H, W, N, R = 260, 346, 300_000, 3
     win = synth.make_window(33, (H, W), N, R, flow='constant', flow_mag=15.0)
     out = {}
@@ -88,9 +89,9 @@ def test_event_order_inside_a_tile_only_moves_roundings(built_lib, monkeypatch):
         p = engine.make_params(20.0, 35.0, 0.0, 0.0, lvl)
         for mode in ('redeal', 'time_order'):
             if mode == 'time_order':
-                monkeypatch.setenv('EINCM_NO_SPREAD', '1')
+                monkeypatch.setenv('EINCM_NO_SEGSORT', '1')
             else:
-                monkeypatch.delenv('EINCM_NO_SPREAD', raising=False)
+                monkeypatch.delenv('EINCM_NO_SEGSORT', raising=False)
             with engine.Engine((H, W), N, max_refs=R) as eng:
                 eng.set_window(*win_args(win))
                 v, g, _ = eng.loss_grad(th, p)
@@ -99,4 +100,4 @@ def test_event_order_inside_a_tile_only_moves_roundings(built_lib, monkeypatch):
         assert np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
         assert np.array_equal(a[0], b[0]), (a[0], b[0])
         np.testing.assert_allclose(a[1], b[1], rtol=0, atol=2e-6 * np.abs(b[1]).max())
-    monkeypatch.delenv('EINCM_NO_SPREAD', raising=False)
+    monkeypatch.delenv('EINCM_NO_SEGSORT', raising=False)
