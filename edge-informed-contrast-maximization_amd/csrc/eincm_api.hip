@@ -125,6 +125,8 @@ struct eincm_ctx {
     double* d_grad = nullptr;      // (B,H,W,2) capacity
     double* d_AH = nullptr; double* d_AW = nullptr;     // (H,h) (W,w) capacity H*H, W*W? -> sized on demand
     int2* d_rowtap = nullptr; int2* d_coltap = nullptr;
+    TileRange* d_tilerng = nullptr;    // (ntiles) coarse cells under each tile for the current theta shape
+    bool proj_in_gather = false;       // every tile touches <= PG_MAXC x PG_MAXC cells: k_gather projects its tile itself
     size_t AH_cap = 0, AW_cap = 0;
     int cur_h = -1, cur_w = -1, cur_method = -1;
     int64_t coarse_cap = 0;        // doubles per window in d_gth halves
@@ -277,7 +279,7 @@ void free_all(eincm_ctx* c) {
     F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax); F(c->d_cntmax); F(c->d_amax); F(c->d_gbound); F(c->d_ticket); F(c->d_coef); F(c->d_Gimg);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
     F(c->d_divparts); F(c->d_g2parts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
-    F(c->d_rowtap); F(c->d_coltap);
+    F(c->d_rowtap); F(c->d_coltap); F(c->d_tilerng);
     for (DevBuf* b : {&c->e_u8, &c->e_g, &c->e_sq, &c->e_misc, &c->e_a, &c->e_b, &c->e_kern, &c->e_out}) { F(b->p); b->bytes = 0; }
     auto FH = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
     FH(c->h_theta); FH(c->h_outs); c->h_grad = nullptr; FH(c->h_wc); FH(c->h_g11); FH(c->h_g2); FH(c->h_img);
@@ -357,6 +359,22 @@ int ensure_resample(eincm_ctx* c, int h, int w, int method) {
     HIPCHK(c, hipMemcpyAsync(c->d_AW, AW.data(), AW.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_rowtap, rt.data(), rt.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_coltap, ct.data(), ct.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    // the coarse cells under every 32x32 tile (what k_gather's own projection walks)
+    const int tilesX = (W + TS - 1) / TS, tilesY = (H + TS - 1) / TS;
+    std::vector<TileRange> tr((size_t)tilesX * tilesY);
+    bool fits = true;
+    for (int ty = 0; ty < tilesY; ++ty)
+        for (int tx = 0; tx < tilesX; ++tx) {
+            int ilo = h, ihi = 0, jlo = w, jhi = 0;
+            for (int y = ty * TS; y < std::min(ty * TS + TS, H); ++y) if (rt[y].y > rt[y].x) { ilo = std::min(ilo, rt[y].x); ihi = std::max(ihi, rt[y].y); }
+            for (int x = tx * TS; x < std::min(tx * TS + TS, W); ++x) if (ct[x].y > ct[x].x) { jlo = std::min(jlo, ct[x].x); jhi = std::max(jhi, ct[x].y); }
+            TileRange q;
+            q.ilo = ilo < ihi ? ilo : 0; q.ni = std::max(ihi - ilo, 0); q.jlo = jlo < jhi ? jlo : 0; q.nj = std::max(jhi - jlo, 0);
+            fits = fits && q.ni <= PG_MAXC && q.nj <= PG_MAXC;
+            tr[(size_t)ty * tilesX + tx] = q;
+        }
+    HIPCHK(c, hipMemcpyAsync(c->d_tilerng, tr.data(), tr.size() * sizeof(TileRange), hipMemcpyHostToDevice, c->stream));
+    c->proj_in_gather = fits && !getenv("EINCM_NO_PROJ_IN_GATHER");
     HIPCHK(c, hipStreamSynchronize(c->stream));     // host vectors go out of scope
     c->cur_h = h; c->cur_w = w; c->cur_method = method;
     return EINCM_OK;
@@ -692,6 +710,7 @@ int eval_end_launch(eincm_ctx* c) {
                            c->d_tvparts, full_aux ? 1 : 0);
     }
     const bool direct11 = want_grad && !identity && h == 1 && w == 1;
+    const bool proj = want_grad && !identity && !direct11 && c->proj_in_gather;      // k_gather projects its tile's sums itself
     // a window with a handful of events: 61-bit fixed point in the per-pixel gradient sums (grad_shift_pixel); speed is irrelevant there
     bool wide = false;
     for (int b = 0; b < g.B; ++b) wide = wide || (c->win_events[b] * (int64_t)g.R < 4096);
@@ -739,28 +758,33 @@ int eval_end_launch(eincm_ctx* c) {
                     gg, n_g, items_g, xy_g, t_g, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_G, wins_g, c->d_gTheta, \
                     direct11 ? 1 : 0, host_asm ? c->h_g11 : c->d_g11, c->d_wc, gmax_buf, direct11 ? THETA_CONST : THETA_TILE, order_g, \
                     c->pend.use_arg ? 1 : 0, c->pend.theta_dev, c->pend.targ, \
-                    ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG ? 1 : 0, c->d_edges, c->d_iwe, c->d_coef, c->d_acc, 1, nparts
+                    ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG ? 1 : 0, c->d_edges, c->d_iwe, c->d_coef, c->d_acc, 1, nparts, \
+                    h, w, c->d_AH, c->d_AW, c->d_tilerng, c->d_gth, (int)c->coarse_cap
+#define GATHER_TILE(WIDE_, COMPOSE_, PROJ_) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, WIDE_, NT_TILE, COMPOSE_, PROJ_>, GATHER_ARGS(NT_TILE))
                 if (direct11) {
-                    if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 1>, GATHER_ARGS(NT));
-                    else         launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 0>, GATHER_ARGS(NT));
+                    if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 1, 0>, GATHER_ARGS(NT));
+                    else         launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 0, 0>, GATHER_ARGS(NT));
                     c->g11_per_item = g.R * nparts;
                 } else if (wide) {
-                    if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 1, NT_TILE, 1>, GATHER_ARGS(NT_TILE));
-                    else         launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 1, NT_TILE, 0>, GATHER_ARGS(NT_TILE));
+                    if (compose) { if (proj) GATHER_TILE(1, 1, 1); else GATHER_TILE(1, 1, 0); }
+                    else         { if (proj) GATHER_TILE(1, 0, 1); else GATHER_TILE(1, 0, 0); }
                 } else {
-                    if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 0, NT_TILE, 1>, GATHER_ARGS(NT_TILE));
-                    else         launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, 0, NT_TILE, 0>, GATHER_ARGS(NT_TILE));
+                    if (compose) { if (proj) GATHER_TILE(0, 1, 1); else GATHER_TILE(0, 1, 0); }
+                    else         { if (proj) GATHER_TILE(0, 0, 1); else GATHER_TILE(0, 0, 0); }
                 }
+#undef GATHER_TILE
 #undef GATHER_ARGS
             }
         }
         // accumulators: two halves (event gradient | TV gradient), each (maxB, coarse_cap) i64, zero on entry (k_final clears them).
         // 2-DoF theta: k_gather left per-workgroup partials of the event gradient for k_final; only the TV image needs projecting.
-        const int nsrc = (direct11 ? 0 : 1) + (ep.use_tv_grad ? 1 : 0);
+        // (a theta grid coarse enough for k_gather's own projection leaves only the TV image to k_project)
+        const bool events_projected = direct11 || proj;
+        const int nsrc = (events_projected ? 0 : 1) + (ep.use_tv_grad ? 1 : 0);
         if (!identity && nsrc > 0) {
             StageTimer t(c, EINCM_STAGE_PROJECT, true);
             launch_timed(c, EINCM_STAGE_PROJECT, k_project, dim3(g.ntiles, g.B, nsrc), dim3(NT), 0, g, h, w,
-                               (int)c->coarse_cap, direct11 ? 1 : 0, wide ? 1 : 0, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_gTheta, c->d_tvg,
+                               (int)c->coarse_cap, events_projected ? 1 : 0, wide ? 1 : 0, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_gTheta, c->d_tvg,
                                c->d_wc, gmax_buf, c->d_gth, c->d_gth + (size_t)c->maxB * c->coarse_cap);
         }
     }
@@ -1123,6 +1147,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(hipMemset(c->d_gth, 0, 2 * B * (size_t)c->coarse_cap * sizeof(long long)));
     TRY(dalloc(&c->d_rowtap, (size_t)H));
     TRY(dalloc(&c->d_coltap, (size_t)W));
+    TRY(dalloc(&c->d_tilerng, (size_t)ntiles));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_theta), B * img * 2 * sizeof(double), hipHostMallocDefault));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_wc), B * sizeof(WinConst), hipHostMallocDefault));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_g11), (size_t)(c->max_items + NXCD) * R * 2 * 4 * sizeof(double), hipHostMallocDefault));

@@ -1504,7 +1504,9 @@ __device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, cons
 // slots in index order).  Otherwise: per-pixel sums are accumulated in an LDS copy of the source tile as i64 fixed point
 // (ds_add_u64; scale grad_shift_pixel) and flushed with i64 global atomics.  Both are bit-reproducible.
 // ------------------------------------------------------------------------------------------------
-template <int TM, int WIDE, int NTH, int COMPOSE>      // NTH threads per workgroup: 256, or 512 where the LDS footprint allows only 3 workgroups per CU (THETA_TILE); TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
+constexpr int PG_MAXC = 6;        // coarse rows / columns under one 32x32 tile that k_gather's own projection handles (16x16 theta on 260x346: 4)
+struct TileRange { int ilo, ni, jlo, nj; };     // the coarse cells a tile's pixels have weight on (host: ensure_resample)
+template <int TM, int WIDE, int NTH, int COMPOSE, int PROJ>      // NTH threads per workgroup: 256, or 512 where the LDS footprint allows only 3 workgroups per CU (THETA_TILE); TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
 __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WIDE: 61-bit fixed point per event (tiny windows, see grad_shift_pixel)
         const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
         const double* __restrict__ Theta, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
@@ -1520,7 +1522,12 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         const ImgCoef* __restrict__ coef,      // (B,R) per-image scalars and |G| bounds from k_imstat's tail
         unsigned long long* __restrict__ acc,  // the u64 IWE accumulator: consumed by k_imstat, cleared here (a slice per workgroup)
         int list_a,                            // the segments walked are the gather's own list (window capacity wincap_a), not the splat's
-        int nparts)                            // 1, 2 or 4 = gridDim.y: workgroups sharing a segment (256-thread form only)
+        int nparts,                            // 1, 2 or 4 = gridDim.y: workgroups sharing a segment (256-thread form only)
+        // PROJ = 1 (theta grids whose tiles touch <= PG_MAXC x PG_MAXC cells): the workgroup projects its tile's sums onto the theta
+        // cells itself, dL/dtheta[i,j] += sum_{y,x} AH[y,i] AW[x,j] dL/dTheta[y,x] (reverse of theta_utils.py:25-35), instead of
+        // flushing them into the dL/dTheta image for k_project: 2 x 32 x 32 global atomics per workgroup become <= 2 ni nj
+        int h, int w, const double* __restrict__ AH, const double* __restrict__ AW, const TileRange* __restrict__ tilerng,
+        long long* __restrict__ gth_main, int gth_cap)
 {
     const int part = blockIdx.y;
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
@@ -1593,6 +1600,7 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         }
     }
     double gscale = 0.0;                          // 2^eg of this window's gradient accumulators
+    double gm_used = 0.0;                         // max |G| (or its bound) the scales derive from
     if (!direct11) {
         double gm;
         if (COMPOSE) {                            // the same R words k_project / k_final* read through gmax_of (gmax_n = R)
@@ -1604,6 +1612,7 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
             gm = gmax_of(gmax + (size_t)it.win * g.gmax_n, g.gmax_n, gms);
         }
         gscale = ldexp(1.0, grad_shift_pixel(wc[it.win], gm, g.R, WIDE != 0));
+        gm_used = gm;
     }
     __syncthreads();
 
@@ -1689,6 +1698,63 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
 #ifdef EINCM_ABL_G_NOFLUSH
     return;
 #endif
+    if (PROJ) {
+        // Separable and ordered, like k_project's staged form: A) every (tile row, coarse column) sums its row against A_W, B) every
+        // cell sums the 32 row results against A_H; fp64 in a fixed order, ONE rounding per (workgroup, cell) into the i64 cell sums
+        // (scale grad_shift), integer atomics across workgroups: bit-reproducible.  The G window is dead by now: its LDS holds the weights.
+        const TileRange tr = tilerng[it.tile];
+        const int ni = tr.ni, nj = tr.nj;
+        double* ahs = reinterpret_cast<double*>(lds);                    // (32, ni)
+        double* aws = ahs + TS * PG_MAXC;                                // (32, nj)
+        double2* st = reinterpret_cast<double2*>(aws + TS * PG_MAXC);    // (2, 32, nj) row results of the two column halves
+        static_assert((2 * TS * PG_MAXC * 8 + 2 * TS * PG_MAXC * 16) <= WIN_CAP_DEFAULT * 4, "the projection's scratch fits the smallest G window");
+        for (int k = threadIdx.x; k < TS * ni; k += NTH) {
+            const int ly = k / ni, i = k - ly * ni;
+            ahs[k] = (y0 + ly < g.H) ? AH[(size_t)(y0 + ly) * h + tr.ilo + i] : 0.0;
+        }
+        for (int k = threadIdx.x; k < TS * nj; k += NTH) {
+            const int lx = k / nj, j = k - lx * nj;
+            aws[k] = (x0 + lx < g.W) ? AW[(size_t)(x0 + lx) * w + tr.jlo + j] : 0.0;
+        }
+        // the sums as doubles at the cell scale, into the (dead) Theta tile: one conversion per pixel by all threads instead of one per
+        // product; pixel (ly, lx) sits at ly * 32 + (lx ^ ly), so that the column walk of step A spreads over the LDS banks
+        const double gmd = gm_used;                                      // the same value k_final derives its scale from (a float read back)
+        const double scale = ldexp(1.0, grad_shift(wc[it.win], gmd, g.R) - grad_shift_pixel(wc[it.win], gmd, g.R, WIDE != 0));
+        for (int p = threadIdx.x; p < TS * TS; p += NTH) {
+            const int ly = p >> 5, lx = p & 31;
+            const long long vx = (long long)accum[p * 2], vy = (long long)accum[p * 2 + 1];       // exact conversions for |.| < 2^53 (always, unless WIDE)
+            thtile[(ly << 5) + (lx ^ ly)] = make_double2((double)vx * scale, (double)vy * scale);
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 2 * TS * nj; k += NTH) {           // A) (column half, tile row, coarse column): 16 products each
+            const int q = k / (TS * nj), kk = k - q * (TS * nj);
+            const int ly = kk / nj, jj = kk - ly * nj;
+            double ax = 0.0, ay = 0.0;
+#pragma unroll 4                                             // (fully unrolled the loops of this block cost the kernel 90 VGPRs: 8 -> 3 waves per SIMD)
+            for (int lx = 16 * q; lx < 16 * q + 16; ++lx) {
+                const double wgt = aws[lx * nj + jj];
+                const double2 v = thtile[(ly << 5) + (lx ^ ly)];
+                ax += wgt * v.x; ay += wgt * v.y;
+            }
+            st[k] = make_double2(ax, ay);
+        }
+        __syncthreads();
+        unsigned long long* __restrict__ out = reinterpret_cast<unsigned long long*>(gth_main) + (size_t)it.win * gth_cap;
+        for (int k = threadIdx.x; k < ni * nj; k += NTH) {               // B) every cell: the 32 row results against A_H
+            const int ii = k / nj, jj = k - ii * nj;
+            double ax = 0.0, ay = 0.0;
+#pragma unroll 4
+            for (int ly = 0; ly < TS; ++ly) {
+                const double wgt = ahs[ly * ni + ii];
+                const double2 v0 = st[ly * nj + jj], v1 = st[TS * nj + ly * nj + jj];
+                ax += wgt * (v0.x + v1.x); ay += wgt * (v0.y + v1.y);
+            }
+            unsigned long long* o = out + ((size_t)(tr.ilo + ii) * w + (tr.jlo + jj)) * 2;
+            if (ax != 0.0) atomicAdd(o, (unsigned long long)fix64_wide(ax));
+            if (ay != 0.0) atomicAdd(o + 1, (unsigned long long)fix64_wide(ay));
+        }
+        return;
+    }
     unsigned long long* __restrict__ gT = reinterpret_cast<unsigned long long*>(gTheta) + (size_t)it.win * g.H * g.W * 2;
     const int tw = min(TS, g.W - x0), th = min(TS, g.H - y0);
     for (int i = threadIdx.x; i < TS * TS * 2; i += NTH) {
