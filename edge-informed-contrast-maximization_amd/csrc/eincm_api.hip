@@ -506,11 +506,23 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
 #define SPLAT_ARGS(NTH) dim3(splat_grid(c)), dim3(NTH), lds_bytes, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
                    c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wins_s, c->d_acc, c->d_order_s, \
                    use_arg ? 1 : 0, theta_dev, targ
-            if (lds_multi)                      launch_timed(c, EINCM_STAGE_SPLAT, k_splat<0, 1, NT>, SPLAT_ARGS(NT));      // long segments (EINCM_SEG_SPLAT > EINCM_CHUNK)
+            static const bool merge_env = getenv("EINCM_SPLAT_MERGE") != nullptr;
+            if (merge_env && !lds_multi && c->seg_used <= MAX_CHUNK && c->n_items > 0) {
+                // experiment: the splat walks the gather's list and copy and merges same-destination taps in registers
+                Geom gs = g; gs.wincap = g.wincap_a; gs.winmaxw = g.winmaxw_a;
+                const size_t lds_m = (size_t)gs.wincap * sizeof(float) + (theta_mode == THETA_TILE ? TS * TS * sizeof(double2) : 0);
+#define MERGE_ARGS dim3(event_grid(c)), dim3(512), lds_m, gs, c->n_items, MAX_CHUNK, theta_mode, 0, \
+                   c->d_items, c->d_xy_g, c->d_t_g, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wins, c->d_acc, c->d_order, \
+                   use_arg ? 1 : 0, theta_dev, targ
+                if (theta_mode == THETA_CONST) launch_timed(c, EINCM_STAGE_SPLAT, k_splat<THETA_CONST, 0, 512, 1>, MERGE_ARGS);
+                else                           launch_timed(c, EINCM_STAGE_SPLAT, k_splat<THETA_TILE, 0, 512, 1>, MERGE_ARGS);
+#undef MERGE_ARGS
+            } else
+            if (lds_multi)                      launch_timed(c, EINCM_STAGE_SPLAT, k_splat<0, 1, NT, 0>, SPLAT_ARGS(NT));      // long segments (EINCM_SEG_SPLAT > EINCM_CHUNK)
             // 512 threads per workgroup in both compile-time modes: 93 vs 94 us on the 8-window batch, 18.8 vs 23.2 us on one window
             // (1024: 102 us; the gather is slower with 512: 93.5 vs 81.7 us)
-            else if (theta_mode == THETA_CONST) launch_timed(c, EINCM_STAGE_SPLAT, k_splat<THETA_CONST, 0, 512>, SPLAT_ARGS(512));
-            else                                launch_timed(c, EINCM_STAGE_SPLAT, k_splat<THETA_TILE, 0, 512>, SPLAT_ARGS(512));
+            else if (theta_mode == THETA_CONST) launch_timed(c, EINCM_STAGE_SPLAT, k_splat<THETA_CONST, 0, 512, 0>, SPLAT_ARGS(512));
+            else                                launch_timed(c, EINCM_STAGE_SPLAT, k_splat<THETA_TILE, 0, 512, 0>, SPLAT_ARGS(512));
 #undef SPLAT_ARGS
         }
     }

@@ -606,7 +606,10 @@ template <int NTH> struct SegWalk {
 // A segment is walked in chunks of <= chunk events; each chunk is accumulated in u32 fixed point (exact integer
 // ds_add_u32) and committed into the segment's f32 window; the window is flushed to HBM once per segment.
 // ------------------------------------------------------------------------------------------------
-template <int TM, int MULTI, int NTH>   // TM: the theta mode as a compile-time constant (0 = run-time argument); MULTI = 0: no segment is longer than a chunk
+// MERGE = 1 is the round-3 experiment "run-merged forward accumulation" (EINCM_SPLAT_MERGE=1): the kernel
+// walks the GATHER's copy of the events (sorted by source pixel inside a segment, a run per thread: SegWalk) and sums the taps of
+// consecutive events of a thread that round to the same destination pixel in nine registers before the nine ds_add_u32.
+template <int TM, int MULTI, int NTH, int MERGE>   // TM: the theta mode as a compile-time constant (0 = run-time argument); MULTI = 0: no segment is longer than a chunk
 __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, int theta_mode, int lds_multi,
         const Item* __restrict__ items,
         const uint32_t* __restrict__ ev_xy,    // x | y << 16, binned by (window, tile)
@@ -720,6 +723,54 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
             __syncthreads();
         }
     };
+    if (MERGE) {
+        int cur_off = -1;                            // LDS word of the top-left tap of the run in the registers (-1: none)
+        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0, m8 = 0;
+        auto flush9 = [&]() {
+            if (cur_off < 0) return;
+            uint32_t* p = ldsu + cur_off; uint32_t* p1 = p + wn.ww; uint32_t* p2 = p1 + wn.ww;
+            atomicAdd(p, m0); atomicAdd(p + 1, m1); atomicAdd(p + 2, m2);
+            atomicAdd(p1, m3); atomicAdd(p1 + 1, m4); atomicAdd(p1 + 2, m5);
+            atomicAdd(p2, m6); atomicAdd(p2 + 1, m7); atomicAdd(p2 + 2, m8);
+        };
+        auto merge_ev = [&](const EvReg& ev) {
+            const double dt = ev.t - tau;
+            const int x = ev.xy & 0xffff, y = ev.xy >> 16;
+            const double2 v = (theta_mode == THETA_CONST) ? vconst : thtile[((ev.xy >> 11) & (31u << 5)) | (ev.xy & 31u)];
+            int irx, iry; float fx, fy;
+            warp_axis(x, v.x, dt, irx, fx);
+            warp_axis(y, v.y, dt, iry, fy);
+            const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;
+            if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
+                f2v km, k0, kp;
+                taps3x2(fx, fy, scy, km, k0, kp);
+                const int off = __mul24(ly, wn.ww) + lx;
+                const uint32_t t0 = fix_u32(km.y, km.x), t1 = fix_u32(km.y, k0.x), t2 = fix_u32(km.y, kp.x);
+                const uint32_t t3 = fix_u32(k0.y, km.x), t4 = fix_u32(k0.y, k0.x), t5 = fix_u32(k0.y, kp.x);
+                const uint32_t t6 = fix_u32(kp.y, km.x), t7 = fix_u32(kp.y, k0.x), t8 = fix_u32(kp.y, kp.x);
+                if (off == cur_off) {                // exact integer adds: the image is bit-identical to the unmerged one
+                    m0 += t0; m1 += t1; m2 += t2; m3 += t3; m4 += t4; m5 += t5; m6 += t6; m7 += t7; m8 += t8;
+                } else {
+                    flush9();
+                    cur_off = off;
+                    m0 = t0; m1 = t1; m2 = t2; m3 = t3; m4 = t4; m5 = t5; m6 = t6; m7 = t7; m8 = t8;
+                }
+            } else {
+                flush9();
+                cur_off = -1;
+                splat_ev(ev);                        // the direct path for taps outside the window
+            }
+        };
+        const SegWalk<512> walk(n, tid);
+        const int c = walk.half;
+        const int K = c ? walk.K1 : walk.K0, rem = c ? walk.rem1 : walk.rem0;
+        const uint32_t* __restrict__ px = exy + (c ? walk.n0 : 0) + walk.tt;
+        const double* __restrict__ pt = et + (c ? walk.n0 : 0) + walk.tt;
+#pragma unroll 2
+        for (int j = 0; j < K - 1; ++j) { EvReg ev; ev.xy = px[j * 256]; ev.t = pt[j * 256]; merge_ev(ev); }
+        if (K > 0 && walk.tt < rem) { EvReg ev; ev.xy = px[(K - 1) * 256]; ev.t = pt[(K - 1) * 256]; merge_ev(ev); }
+        flush9();
+    } else {
     EvReg A, B, C;
     load_ev(A, tid);
     load_ev(B, tid + NTH);
@@ -731,6 +782,7 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         if (j + 2 < iters) step(C, A, B, j + 2);
     }
 #endif
+    }
     if (!multi) __syncthreads();
 #ifdef EINCM_ABL_S_NOFLUSH
     return;
