@@ -561,8 +561,13 @@ int collect_timings(eincm_ctx* c) {
 }
 
 // First half of an evaluation: theta -> Theta -> IWE stack (k_theta, k_splat).  theta_host: (B,h,w,2) doubles.
-int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_params* p, bool want_grad) {
+int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_params* p, bool want_grad, const uint8_t* active = nullptr) {
     HostPhase hp(c, EINCM_HP_BEGIN);
+    {   // which windows take part (eincm_loss_grad_masked); the others' workgroups leave at once, their outputs are not written
+        unsigned long long m = ~0ull;
+        if (active) { m = 0ull; for (int b = 0; b < c->g.B && b < 64; ++b) if (active[b]) m |= 1ull << b; }
+        c->g.wmask = m;
+    }
     const Geom& g = c->g;
     const bool identity = (h == g.H && w == g.W);
     const size_t img = (size_t)g.H * g.W;
@@ -857,6 +862,7 @@ void host_assemble(eincm_ctx* c) {
         const WinConst& wc = c->h_wc[b];
         OutScal& o = c->h_outs[b];
         memset(&o, 0, sizeof o);
+        if (b < 64 && !((g.wmask >> b) & 1ull)) continue;       // sat this evaluation out (eval_end_collect marks its outputs)
         double sum_rel_con = 0.0, sum_rel_corr = 0.0;
         for (int r = 0; r < g.R; ++r) {
             const double* q = c->h_img + ((size_t)b * g.R + r) * IMGSCAL_N;
@@ -939,6 +945,12 @@ int eval_end_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) 
 
     bool nonfinite = false;
     for (int b = 0; b < g.B; ++b) {
+        if (b < 64 && !((g.wmask >> b) & 1ull)) {               // not evaluated: NaN value, zero gradient, no verdict
+            if (value) value[b] = NAN;
+            if (aux) { aux[b].final_loss = NAN; aux[b].mean_rel_corr = NAN; aux[b].mean_rel_contrast = NAN; aux[b].mean_rel_iwe_divergence = NAN; aux[b].theta_total_variation = NAN; }
+            if (want_grad && c->n_pieces == 0) for (size_t i = 0; i < nth; ++i) c->h_grad[(size_t)b * nth + i] = 0.0;
+            continue;
+        }
         const OutScal& o = c->h_outs[b];
         if (value) value[b] = o.value;
         if (aux) {
@@ -982,8 +994,8 @@ int eval_end(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
 
 // The whole evaluation.  theta_host: (B,h,w,2) doubles (already validated).
 int evaluate(eincm_ctx* c, const double* theta_host, int h, int w, const eincm_params* p,
-             double* value, double* grad, eincm_aux* aux, bool /*for_constants*/) {
-    int rc = eval_begin(c, theta_host, h, w, p, grad != nullptr);
+             double* value, double* grad, eincm_aux* aux, bool /*for_constants*/, const uint8_t* active = nullptr) {
+    int rc = eval_begin(c, theta_host, h, w, p, grad != nullptr, active);
     if (rc) return rc;
     return eval_end(c, value, grad, aux);
 }
@@ -1668,6 +1680,18 @@ int eincm_loss_grad(eincm_ctx* c, const double* theta, int h, int w, const eincm
     return evaluate(c, theta, h, w, p, value, grad, aux, false);
 }
 
+int eincm_loss_grad_masked(eincm_ctx* c, const double* theta, int h, int w, const eincm_params* p, const uint8_t* active,
+                           double* value, double* grad, eincm_aux* aux) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!c->staged) return fail(c, EINCM_ERR_STATE, "eincm_loss_grad_masked called before eincm_set_windows");
+    if (c->constants_pending) return fail(c, EINCM_ERR_STATE, "window constants pending (eincm_finish_constants)");
+    if (!theta || !p || !value) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (h < 1 || w < 1) return fail(c, EINCM_ERR_ARG, "theta shape (%d,%d,2) invalid", h, w);
+    if (p->method < 0 || p->method > EINCM_METHOD_CUBIC) return fail(c, EINCM_ERR_ARG, "method %d unknown", p->method);
+    HIPCHK(c, hipSetDevice(c->device));
+    return evaluate(c, theta, h, w, p, value, grad, aux, false, active);
+}
+
 int eincm_handover_loss_grad(eincm_ctx* c, const double* a, const double* prev_theta, const double* theta, int h, int w,
                              const eincm_params* p, double* value, double* dvalue_da) {
     if (!c) return EINCM_ERR_ARG;
@@ -1776,6 +1800,7 @@ static int ensure_theta_image(eincm_ctx* c) {
     const int rc = ensure_resample(c, 1, 1, EINCM_METHOD_BILINEAR);      // a (1,1,2) theta upsamples to a constant with every method
     if (rc) return rc;
     memcpy(c->h_theta, c->last_theta11.data(), c->last_theta11.size() * sizeof(double));
+    c->g.wmask = ~0ull;                              // every window's image, whatever the last evaluation masked
     ThetaArg targ{};
     launch_theta_image(c, 1, 1, false, false, targ, c->h_theta, false);
     HIPCHK(c, hipGetLastError());

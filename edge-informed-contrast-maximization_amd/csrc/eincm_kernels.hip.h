@@ -66,9 +66,13 @@ struct Geom {
     int wincap_a, winmaxw_a;  // the same for the gather's own list (items, "list a"): its segments are longer, so they span more time and move further
     int nparts;               // StatParts per image written by the statistics kernel of this evaluation (ntiles or NSPART)
     int pstride;              // StatPart slots per image: max(ntiles, NSPART, k_imstat workgroups per image)
-    int gmax_n;               // words of `gmax` per window: R * nig per-strip maxima of k_imgrad, or 1 bound written by the composing gather
+    int gmax_n;               // words of `gmax` per window: R * nig per-strip maxima of k_imgrad, or R bounds from k_imstat's tail
+    unsigned long long wmask; // bit b: window b takes part in this evaluation (eincm_loss_grad_masked: a lockstep solver's converged windows
+                              // sit out; their workgroups leave at once and their outputs are not written).  Windows >= 64 always take part.
     int igx, nig;             // k_imgrad strips per image row / per image (IG_COLS x IG_ROWS pixels each): slots of g2parts and gmax
 };
+
+__device__ __forceinline__ bool win_active(const Geom& g, int b) { return b >= 64 || ((g.wmask >> b) & 1ull) != 0ull; }
 
 struct Item {                     // one segment of event work: <= seg events of one source tile of one window
     int32_t win, tile, begin, count;
@@ -386,6 +390,7 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
     const int tile = blockIdx.x, b = blockIdx.y;
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const double* th = theta + (size_t)b * h * w * 2;
+    if (!win_active(g, b)) return;
     double* Th = Theta + (size_t)b * g.H * g.W * 2;
     double mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
     bool nan = false;
@@ -500,6 +505,7 @@ __device__ __forceinline__ void windows_of(const Geom& g, int idx, int n_a, cons
     const int k = first ? idx : idx - n_a * g.R;
     if (!first && k >= n_b * g.R) return;
     const Item it = (first ? items_a : items_b)[k / g.R];
+    if (!win_active(g, it.win)) return;
     const int r = k % g.R;
     double mm4[4];
     if (const_theta) {
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(NT) void k_theta_const(Geom g, int use_arg, ThetaAr
                                                      int n_b, const Item* __restrict__ items_b, Window* __restrict__ wins_b)
 {
     const int i = blockIdx.x * NT + threadIdx.x;
-    if (i < g.B * g.ntiles) {
+    if (i < g.B * g.ntiles && win_active(g, i / g.ntiles)) {
         const int b = i / g.ntiles;
         const double vx = use_arg ? targ.v[2 * b] : theta[2 * b], vy = use_arg ? targ.v[2 * b + 1] : theta[2 * b + 1];
         double* o = tmm + (size_t)i * 4;
@@ -629,6 +635,7 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
     int item, r;
     if (!block_to_work(n_items, g.R, order, item, r)) return;
     const Item it = items[item];
+    if (!win_active(g, it.win)) return;
     const double tau = edge_ts[it.win * g.R + r];
     const int tx0 = (it.tile % g.tilesX) * TS, ty0 = (it.tile / g.tilesX) * TS;
     double2 vconst = make_double2(0.0, 0.0);
@@ -849,6 +856,7 @@ __global__ __launch_bounds__(NT) void k_stats(Geom g, const float* __restrict__ 
     const int x0 = tx * TS, y0 = ty * TS;
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
     const float* __restrict__ E = edges + ((size_t)b * g.R + r) * g.H * g.W;
+    if (!win_active(g, b)) return;
     // with_contrast = 0 (gradient evaluations): k_imgrad computes the Scharr images anyway and accumulates the contrast
     // energy itself, so this kernel is a pure streaming reduction (no LDS tile, no halo, no stencil).
     if (with_contrast) {
@@ -926,6 +934,7 @@ __global__ __launch_bounds__(NT) void k_stats_stream(Geom g, unsigned long long*
     __shared__ double red[NWAVE][8];
     const int part = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
     const size_t n = (size_t)g.H * g.W;
+    if (!win_active(g, b)) return;
     unsigned long long* __restrict__ A = acc + ((size_t)b * g.R + r) * n;
     float* __restrict__ I = iwe + ((size_t)b * g.R + r) * n;
     const float* __restrict__ E = edges + ((size_t)b * g.R + r) * n;
@@ -1039,6 +1048,7 @@ __global__ __launch_bounds__(IG_NT) void k_imgrad(Geom g, EvalParams ep,
     __shared__ double sc[10];
     const bool use_div = (ep.delta != 0.0);
     const int r = blockIdx.y, b = blockIdx.z, lane = threadIdx.x & 63;
+    if (!win_active(g, b)) return;
     const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * (IG_NT / 64) + (threadIdx.x >> 6));   // wave-uniform: row tests stay scalar
     const double HW = (double)g.H * (double)g.W;
     const size_t img = ((size_t)b * g.R + r) * g.H * g.W;
@@ -1224,6 +1234,7 @@ __global__ __launch_bounds__(IG_NT) void k_imstat(Geom g, int gradmag,
     __shared__ int s_last;
     const int r = blockIdx.y, b = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int strip = __builtin_amdgcn_readfirstlane(blockIdx.x * (IG_NT / 64) + wv);   // wave-uniform: row tests stay scalar
+    if (!win_active(g, b)) return;
     const size_t img = ((size_t)b * g.R + r) * g.H * g.W;
     const unsigned long long* __restrict__ Ac = acc + img;
     const float* __restrict__ E = edges + img;
@@ -1361,6 +1372,7 @@ __global__ __launch_bounds__(NT) void k_div(Geom g, const float* __restrict__ iw
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
+    if (!win_active(g, b)) return;
     if (threadIdx.x < 64) {
         const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.pstride, g.nparts);
         if (threadIdx.x == 0) { sc[0] = s.m; sc[1] = s.D; }
@@ -1417,6 +1429,7 @@ __global__ __launch_bounds__(NT) void k_divgrad(Geom g, const float* __restrict_
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
     const float* __restrict__ I = iwe + ((size_t)b * g.R + r) * g.H * g.W;
+    if (!win_active(g, b)) return;
     if (threadIdx.x < 64) {
         const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.pstride, g.nparts);
         if (threadIdx.x == 0) { sc[0] = s.m; sc[1] = s.D; }
@@ -1602,6 +1615,7 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
     int item, r;
     if (!block_to_work(n_items, g.R, order, item, r)) return;
     const Item it = items[item];
+    if (!win_active(g, it.win)) return;
     const double tau = edge_ts[it.win * g.R + r];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool gradmag = gradmag_i != 0;
@@ -1824,6 +1838,7 @@ __global__ __launch_bounds__(NT) void k_compose(Geom g, EvalParams ep, const flo
 {
     __shared__ GCoef sq;
     const int r = blockIdx.y, b = blockIdx.z;
+    if (!win_active(g, b)) return;
     if (threadIdx.x < 64) {
         const ImgScal s = reduce_parts(parts + ((size_t)b * g.R + r) * g.pstride, g.nparts);
         if (threadIdx.x == 0) sq = gcoef_from(s, wc[b], ep, r, g.R, (double)g.H * (double)g.W);
@@ -1931,6 +1946,7 @@ __global__ __launch_bounds__(NT) void k_tv(Geom g, const double* __restrict__ Th
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
     const double* __restrict__ Th = Theta + (size_t)b * g.H * g.W * 2;
+    if (!win_active(g, b)) return;
     const uint8_t* __restrict__ mk = mask + (size_t)b * g.H * g.W;
     for (int p = threadIdx.x; p < P2 * P2; p += NT) {
         const int ly = p / P2, lx = p % P2;
@@ -2062,6 +2078,7 @@ __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, i
     static_assert(PROJ_CELLS * 2 >= TS * TS * 2, "cells doubles as the tile buffer of the staged path");
     __shared__ __attribute__((aligned(16))) unsigned long long cells[PROJ_CELLS * 2 + TS * RS_MAXC * 2];   // staged path: sv (TS*TS double2) + st (TS*nj double2)
     const int tile = blockIdx.x, b = blockIdx.y, src = blockIdx.z + src0;
+    if (!win_active(g, b)) return;
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
     const int x1 = min(x0 + TS, g.W), y1 = min(y0 + TS, g.H);
@@ -2224,6 +2241,7 @@ __global__ __launch_bounds__(FT) void k_final(Geom g, EvalParams ep,
     const int b = blockIdx.x;
     const WinConst& c = wc[b];
     OutScal* __restrict__ o = outs + b;
+    if (!win_active(g, b)) return;
     const double HW = (double)g.H * (double)g.W;
     // This kernel is a latency chain on 8 workgroups; everything that depends on nothing is loaded first so that the loads overlap
     // the per-reference-time reductions: the NaN scan of the velocity bounds and the first partials of the 2-DoF gradient.
@@ -2350,6 +2368,7 @@ __global__ void k_final_dense(Geom g, int use_tv, int wide, long long* __restric
     const int b = blockIdx.y;
     const size_t n = (size_t)g.H * g.W * 2;
     const double s = outs[b].tv_scale;
+    if (!win_active(g, b)) return;
     __shared__ unsigned gms[NWAVE];
     const double inv = ldexp(1.0, -grad_shift_pixel(wc[b], gmax_of(gmax + (size_t)b * g.gmax_n, g.gmax_n, gms), g.R, wide != 0));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

@@ -131,8 +131,9 @@ class Engine:
         self.set_windows([(xs, ys, ts, edges, edge_ts)])
 
     # -- evaluation -------------------------------------------------------------------------------
-    def loss_grad(self, theta, params, want_grad=True, want_aux=False, allow_nonfinite=True):
-        """theta: (B,h,w,2) or (h,w,2) when B == 1.  Returns (value (B,), grad (B,h,w,2) | None, aux list | None)."""
+    def loss_grad(self, theta, params, want_grad=True, want_aux=False, allow_nonfinite=True, active=None):
+        """theta: (B,h,w,2) or (h,w,2) when B == 1.  Returns (value (B,), grad (B,h,w,2) | None, aux list | None).
+        active: optional (B,) mask - only those windows are evaluated (the others: value NaN, gradient 0), at about their share of the cost."""
         th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64))
         if th.ndim == 3:
             th = th[None]
@@ -142,8 +143,15 @@ class Engine:
         value = np.empty(self.B, dtype=np.float64)
         grad = np.empty_like(th) if want_grad else None
         aux = (L.Aux * self.B)() if want_aux else None
-        rc = self._lib.eincm_loss_grad(self._ctx, th.ctypes.data, h, w, C.byref(params), value.ctypes.data,
-                                       grad.ctypes.data if want_grad else None, aux)
+        if active is not None:
+            act = np.ascontiguousarray(np.asarray(active).astype(np.uint8))
+            if act.shape != (self.B,):
+                raise ValueError(f'active must be ({self.B},), got {act.shape}')
+            rc = self._lib.eincm_loss_grad_masked(self._ctx, th.ctypes.data, h, w, C.byref(params), act.ctypes.data, value.ctypes.data,
+                                                  grad.ctypes.data if want_grad else None, aux)
+        else:
+            rc = self._lib.eincm_loss_grad(self._ctx, th.ctypes.data, h, w, C.byref(params), value.ctypes.data,
+                                           grad.ctypes.data if want_grad else None, aux)
         self._check(rc, allow_nonfinite)
         auxl = None
         if want_aux:

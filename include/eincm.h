@@ -167,6 +167,13 @@ int eincm_loss_grad(eincm_ctx* ctx, const double* theta, int h, int w, const ein
 int eincm_loss_grad_async(eincm_ctx* ctx, const double* theta, int h, int w, const eincm_params* p, int want_grad);
 int eincm_loss_grad_wait(eincm_ctx* ctx, double* value, double* grad, eincm_aux* aux);
 
+/* eincm_loss_grad for a SUBSET of the staged windows: active[b] != 0 selects window b (NULL = all).  The workgroups of the other
+ * windows leave at once, so the call costs about what its active windows cost; their value comes back NaN and their gradient zero.
+ * What a lockstep batch solver needs once some of its windows have converged (the reference has no such caller: it solves one window
+ * at a time, src/eincm/solver.py:209-216).  Windows beyond the 64th are always evaluated. */
+int eincm_loss_grad_masked(eincm_ctx* ctx, const double* theta, int h, int w, const eincm_params* p, const uint8_t* active,
+                           double* value, double* grad, eincm_aux* aux);
+
 /* handover_loss_func (losses.py:208-276) and d/d(alpha_handover) = <dL/dtheta_ho, prev - theta>:
  *   theta_ho = a*prev_theta + (1-a)*theta;  a (n_windows), value (n_windows), dvalue_da (n_windows) or NULL */
 int eincm_handover_loss_grad(eincm_ctx* ctx, const double* alpha_handover, const double* prev_theta,

@@ -1,0 +1,110 @@
+"""The lockstep batch solver on the GPU: B windows solved together reach the optima of B sequential
+``MultipleLevelEINCMSolver`` solves, with one batched loss+grad per lockstep tick."""
+import importlib
+from functools import partial
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sol = importlib.import_module('edge-informed-contrast-maximization_amd.solver')
+bsol = importlib.import_module('edge-informed-contrast-maximization_amd.batch_solver')
+losses = importlib.import_module('edge-informed-contrast-maximization_amd.losses')
+synth = importlib.import_module('edge-informed-contrast-maximization_amd.synth')
+
+LOSS = dict(alpha=20.0, beta=35.0, gamma=0.0, delta=0.0, scale_to_sensor_size_method='bilinear')
+HS = {'use_handover': True, 'solve_handover_for_levels': [1, 0], 'use_downscaled_finest_priors': True, 'handover_limits': [0.0, 1.0],
+      'clip_solved_handover': False, 'alpha_handover': 0.67}
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _lib(built_lib):
+    yield built_lib
+    losses.clear_engine_cache()
+
+
+N_SEQ_CALLS = [0]
+
+
+def counting_loss(*a, **k):
+    N_SEQ_CALLS[0] += 1
+    return losses.value_and_grad_loss_func(*a, **k)
+
+
+def sequential_solver(H, W, n_lvls, maxiter, hs):
+    kw = dict(n_pyr_lvls=n_lvls, sensor_size=(H, W), **LOSS)
+    return sol.MultipleLevelEINCMSolver(
+        n_pyr_lvls=n_lvls, theta_opt_maxiters=sol.growing_maxiters(n_lvls, maxiter / 5, maxiter),
+        theta_loss_pfunc=partial(counting_loss, **kw),
+        theta_opt_solver_params={'method': 'BFGS', 'options': {'gtol': 1e-7}, 'n_extra_attempts': {'pyr_lvl_0': 1, 'pyr_lvl_1': 1}},
+        handover_opt_maxiters=sol.growing_maxiters(n_lvls, 4, 20),
+        handover_loss_pfunc=partial(losses.value_and_grad_handover_loss_func, **kw),
+        handover_opt_solver_params={'method': 'L-BFGS-B', 'options': {'gtol': 1e-6}},
+        handover_settings=hs, pyramid_downscale_method='lanczos3', pyramid_upscale_method='repeat', pyramid_bases=[2] * (n_lvls - 1))
+
+
+def batched_solver(B, H, W, n_lvls, maxiter, hs):
+    return bsol.BatchedMultipleLevelEINCMSolver(
+        B, (H, W), n_lvls, sol.growing_maxiters(n_lvls, maxiter / 5, maxiter), LOSS,
+        {'method': 'BFGS', 'options': {'gtol': 1e-7}, 'n_extra_attempts': {'pyr_lvl_0': 1, 'pyr_lvl_1': 1}},
+        handover_opt_maxiters=sol.growing_maxiters(n_lvls, 4, 20), handover_opt_solver_params={'method': 'L-BFGS-B', 'options': {'gtol': 1e-6}},
+        handover_settings=hs, pyramid_downscale_method='lanczos3', pyramid_upscale_method='repeat', pyramid_bases=[2] * (n_lvls - 1))
+
+
+def test_eight_windows_in_lockstep_reach_the_sequential_optima():
+    """8 independent windows, pyramid 1 -> 2 -> 4: the batched solve ends where 8 sequential solves end (the tolerance of
+    test_hip_and_oracle_backends_agree_on_a_small_solve: objective 1e-4 relative, theta 0.05 px), window by window and level by level,
+    with a fraction of the engine calls."""
+    B, H, W, N, R, n_lvls = 8, 96, 128, 12000, 3, 3
+    wins = [synth.make_window(60 + b, (H, W), N, R, flow='constant', flow_mag=3.0 + 0.5 * b) for b in range(B)]
+    args = [(w['xs'], w['ys'], w['ts'], w['edges'], w['edge_ts']) for w in wins]
+    bs = batched_solver(B, H, W, n_lvls, 16, None)
+    bs.set_datasamples(args)
+    out_b = bs.solve()
+    N_SEQ_CALLS[0] = 0
+    for b in range(B):
+        s = sequential_solver(H, W, n_lvls, 16, None)
+        s.set_datasample(*args[b])
+        out_s = s.solve()
+        for k in range(n_lvls):
+            key = f'pyr_lvl_{k}'
+            st_s, st_b = out_s['theta_opt_state_pyr'][key], out_b[b]['theta_opt_state_pyr'][key]
+            assert st_b.fun_val == pytest.approx(st_s.fun_val, rel=1e-4), (b, key)
+            assert np.abs(out_b[b]['final_theta_pyr'][key] - out_s['final_theta_pyr'][key]).max() < 0.05, (b, key)
+        assert set(out_b[b]) == set(out_s)
+        assert out_b[b]['final_theta_pyr']['pyr_lvl_0'].shape == (4, 4, 2)
+        # (the optimum of the objective as written is near, not at, the true flow, and the coarsest level gets four iterations)
+        assert np.abs(out_b[b]['final_theta_pyr'][f'pyr_lvl_{n_lvls - 1}'][0, 0] - wins[b]['flow_gt'][0, 0]).max() < 2.5
+    bs.close()
+    # lockstep: one engine call per tick serves every window that asked (the others are masked out of the call), so the batch needs far
+    # fewer calls than the sequential solves and evaluates no more windows than they do (plus nothing for the riders)
+    n_seq_evals = N_SEQ_CALLS[0]
+    assert bs.n_batch_evals < 0.5 * n_seq_evals, (bs.n_batch_evals, n_seq_evals)
+    assert bs.n_window_evals <= 1.3 * n_seq_evals, (bs.n_window_evals, n_seq_evals)      # (failing line searches end after different counts)
+    print(f'engine calls: batched {bs.n_batch_evals}, sequential {n_seq_evals}; windows evaluated: batched {bs.n_window_evals}')
+
+
+def test_two_sequences_with_handover():
+    """B independent sequences: the second solve of every sequence hands over from its own first solve (solved weights at levels 1, 0
+    like the reference's defaults), and agrees with the sequential solver run on that sequence alone."""
+    B, H, W, N, R, n_lvls = 2, 96, 128, 8000, 3, 3
+    seqs = [[synth.make_window(70 + 10 * b + i, (H, W), N, R, flow='constant', flow_mag=4.0 + b) for i in range(2)] for b in range(B)]
+    tup = lambda w: (w['xs'], w['ys'], w['ts'], w['edges'], w['edge_ts'])
+    bs = batched_solver(B, H, W, n_lvls, 10, HS)
+    outs = []
+    for i in range(2):
+        bs.set_datasamples([tup(seqs[b][i]) for b in range(B)])
+        outs.append(bs.solve())
+    bs.close()
+    for b in range(B):
+        s = sequential_solver(H, W, n_lvls, 10, HS)
+        for i in range(2):
+            s.set_datasample(*tup(seqs[b][i]))
+            o = s.solve()
+        ob = outs[1][b]
+        assert set(ob['ho_opt_state_pyr']) == set(o['ho_opt_state_pyr']) == {'pyr_lvl_1', 'pyr_lvl_0'}
+        for k in range(n_lvls):
+            key = f'pyr_lvl_{k}'
+            assert ob['final_handover_weight_pyr'][key] == pytest.approx(o['final_handover_weight_pyr'][key], abs=0.05), (b, key)
+            assert np.abs(ob['final_theta_pyr'][key] - o['final_theta_pyr'][key]).max() < 0.1, (b, key)

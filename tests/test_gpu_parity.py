@@ -614,3 +614,22 @@ def test_warp_rounds_the_product_first():
         vv, g, _ = eng.loss_grad(th, engine.make_params(20.0, 35.0, 0.0, 0.0, 4))
         assert abs(vv[0] - v_ref) <= TOL * abs(v_ref)
         assert rel(eng.iwes()[0], aux['_iwes']) <= TOL
+
+
+def test_masked_evaluation_matches_the_full_one():
+    """eincm_loss_grad_masked: the windows that take part get exactly the values and gradients of a full evaluation (2-DoF and a
+    theta grid), the others NaN / 0, and the next full evaluation is unaffected (no accumulator is left dirty)."""
+    H, W, N, R, B = 96, 128, 15000, 3, 4
+    wins = [synth.make_window(120 + b, (H, W), N, R, flow='constant', flow_mag=5.0) for b in range(B)]
+    with engine.Engine((H, W), B * N, max_refs=R, max_windows=B) as eng:
+        eng.set_windows([win_args(w) for w in wins])
+        for hw, lvl in (((1, 1), 4), ((4, 4), 1)):
+            th = np.stack([synth.theta_near_truth(120 + b, w, hw) for b, w in enumerate(wins)])
+            p = engine.make_params(20.0, 35.0, 0.0, 0.0, lvl)
+            v0, g0, _ = eng.loss_grad(th, p)
+            mask = np.array([True, False, True, False])
+            v1, g1, _ = eng.loss_grad(th, p, active=mask)
+            assert np.array_equal(v1[mask], v0[mask]) and np.array_equal(g1[mask], g0[mask])
+            assert np.all(np.isnan(v1[~mask])) and np.all(g1[~mask] == 0.0)
+            v2, g2, _ = eng.loss_grad(th, p)
+            assert np.array_equal(v2, v0) and np.array_equal(g2, g0)
