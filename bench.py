@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
-ROUND = 'r02'
+ROUND = 'r03'
 
 
 def algorithmic_bytes(N, R, H, W, dense_theta):
@@ -119,6 +119,150 @@ def kernel_roofline(name, ms, alg_bytes, traffic):
     ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {'kernel': name, 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS,
             'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': ms, 'traffic': traffic}
+
+
+# =====================================================================================================================
+# supplementary legs of the default run (outside the headline's timed region; each one bounded to a second or two)
+# =====================================================================================================================
+def _timed_evals(eng, thetas, p, n=40, spin=0.15):
+    """median wall ms of eng.loss_grad over n calls (theta changes every call), after a clock spin-up."""
+    t_end = time.perf_counter() + spin
+    k = 0
+    while time.perf_counter() < t_end:
+        eng.loss_grad(thetas[k % len(thetas)], p); k += 1
+    ts = []
+    for k in range(n):
+        t0 = time.perf_counter(); eng.loss_grad(thetas[k % len(thetas)], p); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts) * 1e3)
+
+
+def _event_kernel_us(engine, sensor, wins_args, R, thetas, p, n=20):
+    """(k_splat us, k_gather us, step ms) of a batch with HIP events attached to both event kernels."""
+    H, W = sensor
+    with engine.Engine((H, W), sum(len(a[0]) for a in wins_args), max_refs=R, max_windows=len(wins_args), timing='dominant') as e:
+        e.set_windows(wins_args)
+        ms = _timed_evals(e, thetas, p, n=n)
+        e.timings_total(reset=True)
+        for k in range(n):
+            e.loss_grad(thetas[k % len(thetas)], p)
+        acc, cnt = e.timings_total()
+    return acc['splat'] / cnt * 1e3, acc['gather'] / cnt * 1e3, ms
+
+
+def extra_legs(a, synth, engine, wins, base, dev_index, alpha, beta):
+    """The configurations beside the headline that matter to a user of the path: the theta-grid batch step,
+    the single-window latencies at the reference's real sizes, dense theta, the two stress thetas of SURVEY 8(d), and the C4
+    end-to-end solve (lockstep batch solver against sequential solves)."""
+    out = {}
+    H, W = (int(v) for v in a.sensor.split('x'))
+    B, N, R = a.windows_per_gpu, a.events, a.refs
+    args8 = [(wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts']) for wn in wins]
+    ev_bytes = B * event_kernel_algorithmic_bytes(N, R, H, W)
+    try:        # ---- the same batch at a 16x16 theta (pyramid level 0: where the solver spends most of its evaluations)
+        th16 = np.stack([synth.theta_near_truth(1000 + b, wn, (16, 16)) for b, wn in enumerate(wins)])
+        p1 = engine.make_params(alpha, beta, 0.0, 0.0, 1)
+        sp, ga, ms = _event_kernel_us(engine, (H, W), args8, R, [th16 * (1.0 + 0.01 * (k - 3)) for k in range(7)], p1)
+        dom = 'k_gather' if ga >= sp else 'k_splat'
+        out['ms_per_step_pyr16'] = ms
+        out['pyr16'] = {'workload': f'{B}x[{H}x{W} N={N} R={R} theta=16x16]', 'k_splat_us': sp, 'k_gather_us': ga, 'dominant': dom,
+                        'dominant_frac_of_hbm_peak': ev_bytes / (max(sp, ga) * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                        'warped_events_per_s': B * N * R / (ms * 1e-3)}
+    except Exception as exc:          # noqa: BLE001 - a supplementary leg must not take the bench line down
+        out['pyr16'] = {'error': repr(exc)[:200]}
+    try:        # ---- stress thetas of SURVEY 8(d): theta = 0, and a theta that sends ~20 % of the events out of the frame
+        p4 = engine.make_params(alpha, beta, 0.0, 0.0, 4)
+        zero = np.zeros_like(base)
+        sp0, ga0, ms0 = _event_kernel_us(engine, (H, W), args8, R, [zero], p4, n=10)
+        big = base.copy()
+        mag = np.linalg.norm(base.reshape(B, 2), axis=1).reshape(B, 1, 1, 1) + 1e-9
+        big = base / mag * 0.45 * min(H, W)                  # |v dt| up to 0.45 min(H, W) px over the window: a fifth of the events leave
+        sp1, ga1, ms1 = _event_kernel_us(engine, (H, W), args8, R, [big], p4, n=10)
+        out['stress_theta'] = {'zero': {'k_splat_us': sp0, 'k_gather_us': ga0, 'ms_per_step': ms0},
+                               'large_20pct_out_of_frame': {'k_splat_us': sp1, 'k_gather_us': ga1, 'ms_per_step': ms1,
+                                                            'theta_px_per_window': float(0.45 * min(H, W))}}
+    except Exception as exc:          # noqa: BLE001
+        out['stress_theta'] = {'error': repr(exc)[:200]}
+    try:        # ---- the reference's real MVSEC size: 256x336, 30 000 events, R = 5, 16x16 theta (run.sh:46,49; dataset/mvsec.yaml:1-2)
+        wm = synth.make_window(77, (256, 336), 30000, 5, flow='smooth', flow_mag=8.0)
+        thm = synth.theta_near_truth(77, wm, (16, 16))
+        with engine.Engine((256, 336), 30000, max_refs=5, max_windows=1, device=dev_index) as e:
+            e.set_window(wm['xs'], wm['ys'], wm['ts'], wm['edges'], wm['edge_ts'])
+            out['eval_ms_mvsec_real_16x16'] = _timed_evals(e, [thm * (1.0 + 0.01 * k) for k in range(5)], engine.make_params(alpha, beta, 0.0, 0.0, 1))
+            out['eval_ms_mvsec_real_2dof'] = _timed_evals(e, [synth.theta_near_truth(77, wm, (1, 1)) * (1.0 + 0.01 * k) for k in range(5)],
+                                                          engine.make_params(alpha, beta, 0.0, 0.0, 4))
+    except Exception as exc:          # noqa: BLE001
+        out['eval_ms_mvsec_real_16x16'] = {'error': repr(exc)[:200]}
+    try:        # ---- C3: 480x640, 10^6 events, R = 3, dense theta (the float64 theta and gradient cross PCIe: 4.9 MB each way)
+        wd = synth.make_window(78, (480, 640), 1_000_000, 3, flow='smooth', flow_mag=20.0)
+        thd = np.ascontiguousarray(wd['flow_gt'])
+        with engine.Engine((480, 640), 1_000_000, max_refs=3, max_windows=1, device=dev_index) as e:
+            e.set_window(wd['xs'], wd['ys'], wd['ts'], wd['edges'], wd['edge_ts'])
+            ths = [np.ascontiguousarray(thd * (1.0 + 0.01 * k)) for k in range(3)]
+            out['eval_ms_c3_dense'] = _timed_evals(e, ths, engine.make_params(alpha, beta, 0.0, 0.0, 0), n=15)
+    except Exception as exc:          # noqa: BLE001
+        out['eval_ms_c3_dense'] = {'error': repr(exc)[:200]}
+    try:        # ---- C4 end to end: the 5-level solve of the 8 windows, lockstep batch solver against sequential solves
+        out['c4_solve'] = c4_solve_leg(a, wins, (H, W), alpha, beta, dev_index)
+        out['c4_solve_windows_per_s'] = out['c4_solve']['batched']['windows_per_s']
+    except Exception as exc:          # noqa: BLE001
+        out['c4_solve'] = {'error': repr(exc)[:300]}
+    return out
+
+
+def c4_solve_leg(a, wins, sensor, alpha, beta, dev_index, n_lvls=5, maxiter=40):
+    """Pyramid 1 -> 16 with the reference's iteration budget (40, 28, 19, 11, 8; configs/main.yaml:35-50), handover off (independent
+    windows): B windows by BatchedMultipleLevelEINCMSolver (one masked engine call per lockstep tick) and the same windows one after
+    the other by MultipleLevelEINCMSolver (SciPy BFGS, one engine call per evaluation)."""
+    from functools import partial
+    sol = importlib.import_module('edge-informed-contrast-maximization_amd.solver')
+    bsol = importlib.import_module('edge-informed-contrast-maximization_amd.batch_solver')
+    losses = importlib.import_module('edge-informed-contrast-maximization_amd.losses')
+    B = len(wins)
+    args = [(wn['xs'], wn['ys'], wn['ts'], wn['edges'], wn['edge_ts']) for wn in wins]
+    loss = dict(alpha=alpha, beta=beta, gamma=0.0, delta=0.0, scale_to_sensor_size_method='bilinear')
+    maxit = sol.growing_maxiters(n_lvls, maxiter / 5, maxiter)
+    sp = {'method': 'BFGS', 'options': {'gtol': 1e-7}, 'n_extra_attempts': {'pyr_lvl_0': 1, 'pyr_lvl_1': 1}}
+    bs = bsol.BatchedMultipleLevelEINCMSolver(B, sensor, n_lvls, maxit, loss, sp, pyramid_bases=[2] * (n_lvls - 1), device=dev_index)
+    t0 = time.perf_counter()
+    bs.set_datasamples(args)
+    t_stage = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out_b = bs.solve()
+    t_b = time.perf_counter() - t0
+    calls_b, wins_b = bs.n_batch_evals, bs.n_window_evals
+    bs.close()
+    n_seq = min(B, 3)                                   # the sequential side on a sample of the windows (SciPy's n^3 update at 16x16 is slow)
+    n_calls = [0]
+
+    def counting(*aa, **kk):
+        n_calls[0] += 1
+        return losses.value_and_grad_loss_func(*aa, **kk)
+    t_s, fin_s, fin_b = 0.0, [], []
+    for b in range(n_seq):
+        s = sol.MultipleLevelEINCMSolver(n_pyr_lvls=n_lvls, theta_opt_maxiters=maxit,
+                                         theta_loss_pfunc=partial(counting, n_pyr_lvls=n_lvls, sensor_size=sensor, **loss),
+                                         theta_opt_solver_params=sp, pyramid_bases=[2] * (n_lvls - 1))
+        s.set_datasample(*args[b])
+        losses.engine_for(*args[b], sensor)              # staging outside the timer, like the batched side
+        t0 = time.perf_counter()
+        o = s.solve()
+        t_s += time.perf_counter() - t0
+        fin_s.append(float(o['theta_opt_state_pyr']['pyr_lvl_0'].fun_val))
+        fin_b.append(float(out_b[b]['theta_opt_state_pyr']['pyr_lvl_0'].fun_val))
+    losses.clear_engine_cache()
+    return {'workload': f'{B} independent windows, pyramid 1..16, BFGS maxiter 40/28/19/11/8 + 1 retry at levels 0, 1, handover off',
+            'batched': {'seconds': t_b, 'windows_per_s': B / t_b, 'engine_calls': calls_b, 'windows_evaluated': wins_b, 'staging_s': t_stage},
+            'sequential': {'seconds_per_window': t_s / n_seq, 'windows_per_s': n_seq / t_s, 'engine_calls_per_window': n_calls[0] / n_seq,
+                           'windows_timed': n_seq},
+            'speedup': (n_seq / t_s) and (B / t_b) / (n_seq / t_s),
+            'final_loss_level0': {'sequential': fin_s, 'batched_same_windows': fin_b, 'batched_mean_all_windows':
+                                  float(np.mean([o['theta_opt_state_pyr']['pyr_lvl_0'].fun_val for o in out_b]))},
+            'final_loss_note': 'the two drivers run the same algorithm; their end points differ where a line search fails on the fp32-level noise '
+                               'of the objective (BFGS status 2 at the start of a level) - which of the two then makes progress is decided by '
+                               'rounding (the reference itself needs float64 for this, configs/main.yaml:34).  tests/test_gpu_batch_solver.py '
+                               'compares them on windows where both converge',
+            'note': 'the batched driver restates SciPy BFGS with the O(n^2) form of the inverse-Hessian update above 64 unknowns; SciPy itself '
+                    'forms two n x n products per iteration (n = 512 at 16x16), which is most of the sequential time at the finest level'}
 
 
 # =====================================================================================================================
@@ -257,13 +401,13 @@ def bench_windows(a):
         roof.update({'bound': 'hbm',
                      'bound_note': 'priced against HBM as the contract asks; the kernels are NOT HBM-bound at these sizes: k_splat is bound by the '
                                    'LDS atomic unit (ablation: deleting its arithmetic leaves its time unchanged), k_gather by VALU issue '
-                                   f'(profiles/{ROUND}/splat_bound_experiment.txt, DESIGN.md section 4.2)',
+                                   '(profiles/r02/splat_bound_experiment.txt, DESIGN.md section 4.2)',
                      'event_kernels': kern,
                      'lds_atomic_lane_ops_per_clk_per_cu': (9.0 * B * N * R / (kern['k_splat']['avg_launch_ms'] * 1e-3) / 256 / 2.4e9)
                      if kern['k_splat']['avg_launch_ms'] > 0 else 0.0,
                      'lds_atomic_peak_lane_ops_per_clk_per_cu': [5.9, 7.4],
                      'lds_atomic_note': '9 ds_add_u32 per warped event; peak = tools/lds_atomic_bench2.hip with the splat\'s own tap pattern '
-                                        f'(destinations on 300 sites, uniform destinations), profiles/{ROUND}/splat_bound_experiment.txt'})
+                                        '(destinations on 300 sites, uniform destinations), profiles/r02/splat_bound_experiment.txt'})
         out = {
             'metric': 'warped-events/sec/GPU + loss+grad eval ms, 1e6 events @ 346x260',
             'value': value, 'unit': 'warped-events/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -277,7 +421,10 @@ def bench_windows(a):
             'roofline': roof,
             'eval_roofline': {'achieved': eval_bytes / (ms_per_step * 1e-3) / 1e9, 'unit': 'GB/s',
                               'frac': eval_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                              'algorithmic_bytes_per_step': eval_bytes},
+                              'algorithmic_bytes_per_step': eval_bytes,
+                              'byte_model_note': 'SURVEY 8(d) prices an event at 8 B and an image pixel at 4 B; the kernels read 12 B per event '
+                                                 '(u32 xy + f64 t) and flush into a u64 accumulator, so the real traffic is higher (roofline.traffic) '
+                                                 'and these fractions are conservative'},
             'device_ms_per_step': round(sum(vv for k, vv in diag.items() if k != 'total'), 4),
             'device_ms_note': 'sum of the kernels\' own durations (diagnostic pass); ms_per_step minus this is host turn-around + launch gaps',
             'stage_ms_per_step': {k: round(vv, 4) for k, vv in diag.items()},
@@ -343,6 +490,8 @@ def bench_windows(a):
                                       'note': 'same 8 windows, 4 engine contexts each driven by its own host thread without a '
                                               'join between steps; supplementary, not the headline'}
 
+    if rank == 0 and world == 1 and not a.no_latency and not dense and a.theta == '1x1':
+        out.update(extra_legs(a, synth, engine, wins, base, dev_index, alpha, beta))
     # ---- CPU baselines: ports of the reference arithmetic (the reference itself, JAX, cannot run here or on the GPU box) ----
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(wins[0], theta_at, alpha, beta, (H, W), N, R, dense)
@@ -354,8 +503,8 @@ def bench_windows(a):
 
 
 def cpu_baseline(wn, theta_at, alpha, beta, sensor, N, R, dense):
-    """CPU-C = the C / OpenMP fp64 port (oracle/eincm_ref.c) on 16 threads (the box's nominal CPU share) and
-    on every host core; CPU-B = the torch-CPU fp64 restatement differentiated by autograd on all cores; CPU-A = the numpy oracle on
+    """CPU-C = the C / OpenMP fp64 port (oracle/eincm_ref.c) on 16 threads (the box's CPU quota; one thread per
+    logical CPU only oversubscribes the quota and is no baseline: dropped in round 3); CPU-B = the torch-CPU fp64 restatement differentiated by autograd on all cores; CPU-A = the numpy oracle on
     one core.  Bounded samples (about 20 s in all)."""
     import torch
     from oracle import eincm_oracle as O
@@ -381,17 +530,6 @@ def cpu_baseline(wn, theta_at, alpha, beta, sensor, N, R, dense):
            'sample': f'{n_eval} loss+grad evaluations of 1 window ({H}x{W}, N={N}, R={R}) by the C/OpenMP fp64 port '
                      f'(oracle/eincm_ref.c, {cores} threads), {t_cpu:.1f} s',
            'eval_ms': t_cpu / n_eval * 1e3, 'host_cores_available': ncpu}
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except AttributeError:
-        usable = ncpu
-    if usable > cores:                  # every logical CPU this process may run on (a 1-GPU box: 256 logical CPUs, CPU quota of 16)
-        t0 = time.perf_counter()
-        CP.loss_and_grad(theta_at(1)[0], *cargs, alpha, beta, (H, W), nthreads=usable)
-        t_all = time.perf_counter() - t0
-        res['all_cores'] = {'value': N * R / t_all, 'cores': usable, 'eval_ms': t_all * 1e3,
-                            'sample': f'1 evaluation, {t_all:.1f} s, the same port with one thread per logical CPU (beyond the process\'s CPU '
-                                      'quota the threads only contend)'}
     try:                                # CPU-B: torch fp64 forward + autograd; bounded sample: the first 1e5 events of the window
         torch.set_num_threads(cores)
         lvl = 4 if not dense else 0
@@ -514,6 +652,8 @@ def bench_event_sharded(a):
                        'events_per_window': N, 'n_refs': R, 'sensor': [H, W], 'theta_levels': levels,
                        'parallelism': f'event-sharded x{world}: all-reduce(sum) of the int64 IWE accumulator + of the gradient per evaluation',
                        'backend': backend},
+            'warped_events_per_s_per_gpu': value / world,
+            'value_note': 'strong scaling: `value` is the aggregate over all ranks (N R / step time); divide by n_gpus for the per-GPU rate',
             'allreduce_bytes_per_evaluation': {'iwe_accumulator_int64': iwe_bytes, 'gradient_fp64_max': 16 * 16 * 2 * 8},
             'set_windows_s': t_stage,
             'solve_50_iters_s' if a.solve_iters == 50 else 'solve_s': solve,

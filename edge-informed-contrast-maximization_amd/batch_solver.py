@@ -24,6 +24,7 @@ from .engine import Engine, make_params
 from .solver import ScipyMinimizeInfo, EmptyCallback, rescale_theta, _canon
 
 _BFGS_C1, _BFGS_C2, _BFGS_XTOL, _BFGS_AMIN, _BFGS_AMAX, _LS_MAXITER = 1e-4, 0.9, 1e-14, 1e-100, 1e100, 100
+_EXACT_UPDATE_MAX_N = 64          # up to this many unknowns the inverse-Hessian update is SciPy's own expression (two n x n products)
 
 
 class _CoroutineCall:
@@ -200,7 +201,7 @@ class _WindowBFGS:
             return self._finish()
         rhok_inv = float(np.dot(yk, sk))
         rhok = 1000.0 if rhok_inv == 0.0 else 1.0 / rhok_inv
-        if self.n <= 64:                                           # SciPy's own expression (bit for bit the same inverse Hessian)
+        if self.n <= _EXACT_UPDATE_MAX_N:                          # SciPy's own expression (bit for bit the same inverse Hessian)
             I = np.eye(self.n, dtype=int)
             A1 = I - sk[:, np.newaxis] * yk[np.newaxis, :] * rhok
             A2 = I - yk[:, np.newaxis] * sk[np.newaxis, :] * rhok
