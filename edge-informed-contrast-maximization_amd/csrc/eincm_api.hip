@@ -1222,6 +1222,9 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     if (N > c->maxN) return fail(c, EINCM_ERR_ARG, "total events %lld exceed capacity %lld", (long long)N, (long long)c->maxN);
     c->staged = false;
     c->Theta_valid = false;
+    // Async copies below read from / write into locals of this function; whatever path leaves it (an error return included), the
+    // stream is drained first (safe before only because pageable copies happen to be host-synchronous).
+    struct DrainOnExit { hipStream_t s; ~DrainOnExit() { (void)hipStreamSynchronize(s); } } drain_on_exit{c->stream};
     if (c->acc_dirty) { const int rcd = clear_accumulators(c); if (rcd) return rcd; }
     Geom g{};
     g.H = H; g.W = W; g.R = n_refs; g.B = n_windows;
@@ -1929,13 +1932,13 @@ int eincm_tiled_objectives(eincm_ctx* c, int tile_h, int tile_w, eincm_tiled_out
         return fail(c, EINCM_ERR_ARG, "tile %d x %d does not fit the %d x %d sensor", tile_h, tile_w, g.H, g.W);
     HIPCHK(c, hipSetDevice(c->device));
     const int ntx = g.W / tile_w, nty = g.H / tile_h, ntl = ntx * nty;
-    const size_t n_t = (size_t)g.B * g.R * ntl * 3, n_p = (size_t)g.B * g.R * 3;
+    const int nb = std::min((g.H * g.W + NT - 1) / NT, 256);
+    const size_t n_t = (size_t)g.B * g.R * ntl * 3, n_p = (size_t)g.B * g.R * nb * 3;
     ENSURE(c, c->e_out, (n_t + n_p) * 8);
     double* d_t = static_cast<double*>(c->e_out.p);
     double* d_p = d_t + n_t;
-    HIPCHK(c, hipMemsetAsync(d_p, 0, n_p * 8, c->stream));
+    g.wmask = ~0ull;
     hipLaunchKernelGGL(k_tiled, dim3(ntl, g.R, g.B), dim3(NT), 0, c->stream, g, tile_h, tile_w, ntx, c->d_iwe, c->d_edges, c->d_parts, d_t);
-    const int nb = std::min((g.H * g.W + NT - 1) / NT, 256);
     hipLaunchKernelGGL(k_pair_objectives, dim3(nb, g.R, g.B), dim3(NT), 0, c->stream, g, c->d_iwe, c->d_edges, c->d_parts, d_p);
     HIPCHK(c, hipGetLastError());
     std::vector<double> hv(n_t + n_p);
@@ -1953,7 +1956,11 @@ int eincm_tiled_objectives(eincm_ctx* c, int tile_h, int tile_w, eincm_tiled_out
                 o.adaptive_variance[r] += t[k * 3 + 1];
                 o.adaptive_mean_squared_error[r] += t[k * 3 + 2];
             }
-            const double* q = hv.data() + n_t + ((size_t)b * g.R + r) * 3;
+            double q[3] = {0.0, 0.0, 0.0};                       // the workgroups' partials, added in index order
+            for (int k = 0; k < nb; ++k) {
+                const double* pk = hv.data() + n_t + (((size_t)b * g.R + r) * nb + k) * 3;
+                q[0] += pk[0]; q[1] += pk[1]; q[2] += pk[2];
+            }
             o.sum_squared_error[r] = q[0];
             o.sum_hadamard_product[r] = q[1];
             o.mean_hadamard_product[r] = q[1] / HW;

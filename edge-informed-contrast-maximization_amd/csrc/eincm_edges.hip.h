@@ -164,8 +164,9 @@ __global__ __launch_bounds__(NT) void k_tiled(Geom g, int th, int tw, int ntx, c
     }
 }
 
-// Untiled siblings on (edge E, normalised IWE n).  grid (nblk, R, B); out (B,R,3) zeroed: sum (E-n)^2, sum E*n,
-// sum |Scharr(E+n)|^2 (whole image, zero padded).
+// Untiled siblings on (edge E, normalised IWE n).  grid (nblk, R, B); out (B,R,nblk,3): every workgroup's partial of sum (E-n)^2,
+// sum E*n, sum |Scharr(E+n)|^2 (whole image, zero padded), stored in its own slot; the host adds the slots in index order (no float
+// atomics anywhere: an fp64 atomicAdd is a compare-and-swap loop here and its sum depends on the arrival order).
 __global__ __launch_bounds__(NT) void k_pair_objectives(Geom g, const float* __restrict__ iwe, const float* __restrict__ edges,
                                                          const StatPart* __restrict__ parts, double* __restrict__ out)
 {
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(NT) void k_pair_objectives(Geom g, const float* __r
     }
     sse = block_sum(sse, scratch); had = block_sum(had, scratch); jc = block_sum(jc, scratch);
     if (threadIdx.x == 0) {
-        double* o = out + ((size_t)b * g.R + r) * 3;
-        atomicAdd(o, sse); atomicAdd(o + 1, had); atomicAdd(o + 2, jc);
+        double* o = out + (((size_t)b * g.R + r) * gridDim.x + blockIdx.x) * 3;
+        o[0] = sse; o[1] = had; o[2] = jc;
     }
 }
 

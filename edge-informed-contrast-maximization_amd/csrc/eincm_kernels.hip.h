@@ -37,8 +37,9 @@ constexpr double EPSN = 2.220446049250313e-16;   // sys.float_info.epsilon (loss
 constexpr float INV_2PI = 0.15915494309189535f;
 // LDS accumulation of the splat is u32 fixed point: on gfx950 ds_add_f32 retires ~1 lane per 3 clocks whatever the
 // address pattern (0.33 lane-ops/clk/CU measured, tools/lds_atomic_bench.hip) while ds_add_u32 sustains 5-7.4.
-// One tap is <= 1/(2*pi) = 0.1592 and an item holds <= MAX_CHUNK events, so a window pixel is < 4096*0.1592 = 652
-// < 2^32 / FIX_SCALE = 1024: the integer sum cannot overflow.  Resolution 2^-22 = 2.4e-7 (round to nearest, unbiased).
+// One tap is <= 1/(2*pi) = 0.1592 and a chunk holds <= MAX_CHUNK events, so with the scale 2^k of fix_shift (the largest power of two
+// with count * 0.16 * 2^k <= 2^32: k = 21 at 8192 events, 22 at 4096) the integer sum of a window pixel cannot overflow.
+// Resolution 2^-k (round to nearest, unbiased): 4.8e-7 absolute per tap at 8192 events.
 constexpr int MAX_CHUNK = 16384;   // events per inner chunk (bounds the u32 sums; the fixed-point scale follows the count, fix_shift)
 constexpr int MAX_SEG = 1 << 20;   // events per segment (one window flush per segment and reference time)
 // Per-item scale 2^k, the largest power of two with count * 0.16 * 2^k <= 2^32 (k capped at 30, where the smallest

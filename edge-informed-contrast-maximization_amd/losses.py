@@ -13,8 +13,9 @@ engine cannot be traced, so the gradient is exposed explicitly as ``value_and_gr
 
 The event window is staged on the GPU once and reused for every evaluation, like the reference's closed-over
 device-resident ``*args``: engines are cached by the identity of the (xs, ys, ts, edges, edge_ts) arrays.  JAX arrays are
-immutable, numpy arrays are not: an in-place edit of a cached array is caught by a cheap content fingerprint (a strided
-sample of every array) and the window is staged again.
+immutable, numpy arrays are not: a cheap content fingerprint (<= 4096 strided samples of every array plus its last element)
+is a BEST-EFFORT check for in-place edits - an edit of a few elements between two calls can go unnoticed, and the stale
+staged window would then be evaluated.  Code that edits a cached array in place calls ``clear_engine_cache()``.
 """
 import weakref
 
@@ -35,10 +36,10 @@ def _fingerprint(arrs):
     """Content check of the cached arrays: <= 4096 strided samples of each plus first/last element, as bytes."""
     parts = []
     for a in arrs:
-        f = a.reshape(-1)
-        if f.size:
-            parts.append(np.ascontiguousarray(f[::max(1, f.size // 4096)]).tobytes())
-            parts.append(f[-1:].tobytes())
+        if a.size:
+            f = a.flat                                           # no copy of a non-contiguous array
+            parts.append(np.asarray(f[::max(1, a.size // 4096)]).tobytes())
+            parts.append(np.asarray(f[a.size - 1]).tobytes())
     return hash(tuple(parts))
 
 

@@ -92,3 +92,22 @@ def test_bench_batch_c4_share():
             e1.set_window(*win_args(wins[b]))
             vb, gb, _ = e1.loss_grad(th[b], engine.make_params(20.0, 35.0, 0.0, 0.0, 4))
             assert vb[0] == pytest.approx(v[b], rel=1e-6) and rel(gb[0], g[b]) <= 1e-5
+
+
+@pytest.mark.parametrize('hw', [(16, 16), 'dense'], ids=['pyr16', 'dense'])
+def test_hot_pixel_keeps_the_gradient_tolerance(hw):
+    """the i64 scale of the per-pixel gradient sums follows the most events on ONE source pixel (WinConst.cntmax), so a hot
+    pixel coarsens the rounding step of every other pixel of the window.  10^4 of 10^6 events on one pixel (real sensors have such
+    pixels; every other test window is near-uniform), theta grid and dense theta, against the C port at the 1e-5 bar."""
+    H, W, N, R = 260, 346, 1_000_000, 5
+    win = synth.make_window(31, (H, W), N, R, flow='smooth', flow_mag=15.0)
+    rng = np.random.default_rng(31)
+    hot = rng.choice(N, 10_000, replace=False)
+    xs, ys = win['xs'].copy(), win['ys'].copy()
+    xs[hot] = 201; ys[hot] = 97
+    win = dict(win, xs=xs, ys=ys)
+    th = win['flow_gt'] * rng.uniform(0.5, 1.5, (H, W, 2)) if hw == 'dense' else synth.theta_near_truth(31, win, hw)
+    with engine.Engine((H, W), N, max_refs=R) as eng:
+        eng.set_window(*win_args(win))
+        v, g, _ = eng.loss_grad(th, engine.make_params(20.0, 35.0, 0.0, 0.0, 0))
+        check_window(eng, 0, th, win, 20.0, 35.0, v, g, eng.iwes(), eng.image_grad())
