@@ -89,6 +89,10 @@ SIGNATURES = [
     ('eincm_forward_iwe', C.c_int, [_P, _D, C.c_int, C.c_int, C.POINTER(Params), C.c_int]),
     ('eincm_finish_loss_grad', C.c_int, [_P, _D, _D, C.POINTER(Aux)]),
     ('eincm_finish_constants', C.c_int, [_P]),
+    ('eincm_set_device_results', C.c_int, [_P, C.c_int]),
+    ('eincm_finish_launch', C.c_int, [_P]),
+    ('eincm_grad_device_ptr', C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    ('eincm_finish_collect', C.c_int, [_P, _D, _D, C.POINTER(Aux)]),
     ('eincm_iwe_device_ptr', C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     ('eincm_mask_device_ptr', C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     ('eincm_inv_dist_transform', C.c_int, [_P, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_double, _D,

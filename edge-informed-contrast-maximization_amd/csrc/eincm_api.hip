@@ -126,6 +126,7 @@ struct eincm_ctx {
     double* d_AH = nullptr; double* d_AW = nullptr;     // (H,h) (W,w) capacity H*H, W*W? -> sized on demand
     int2* d_rowtap = nullptr; int2* d_coltap = nullptr;
     TileRange* d_tilerng = nullptr;    // (ntiles) coarse cells under each tile for the current theta shape
+    bool device_results = false;       // eincm_set_device_results: results stay in HBM until eincm_finish_collect (event-sharded mode over RCCL)
     bool proj_in_gather = false;       // every tile touches <= PG_MAXC x PG_MAXC cells: k_gather projects its tile itself
     size_t AH_cap = 0, AW_cap = 0;
     int cur_h = -1, cur_w = -1, cur_method = -1;
@@ -172,6 +173,7 @@ struct eincm_ctx {
     struct { bool active = false; bool launched = false; EvalParams ep{}; int h = 0, w = 0; bool identity = false, want_grad = false, full_aux = false, div_grad = false;
              bool host_asm = false;                 // scalar assembly and the 2-DoF gradient sum on the host (see h_g11)
              bool composed = false;                 // k_imstat + composing gather (host_assemble: the contrast energy rides in h_img)
+             int copy_mode = 0;                     // 1: the D2H copies of the results are still to be enqueued (device_results)
              bool use_arg = false; const double* theta_dev = nullptr; ThetaArg targ{};      // where the event kernels find a 2-DoF theta
              } pend;
     std::vector<uint8_t> theta_nan;    // (B) a NaN / Inf somewhere in window b's theta (host-assembled evaluations)
@@ -652,7 +654,7 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     // 2-DoF theta with nothing but the contrast and correlation terms (every level above 0 of the reference's pyramid at its first
     // level, and the bench workload): the scalar assembly and the sum of the gather's per-workgroup partials run on the host
     static const bool no_host_asm = getenv("EINCM_NO_HOST_ASM") != nullptr;
-    const bool host_asm = want_grad && !identity && h == 1 && w == 1 && !ep.want_div && !ep.want_tv && !full_aux && !no_host_asm;
+    const bool host_asm = want_grad && !identity && h == 1 && w == 1 && !ep.want_div && !ep.want_tv && !full_aux && !no_host_asm && !c->device_results;
     if (host_asm) {
         c->theta_nan.assign((size_t)g.B, 0);
         for (int b = 0; b < g.B; ++b) c->theta_nan[b] = !(std::isfinite(theta_host[2 * b]) && std::isfinite(theta_host[2 * b + 1]));
@@ -661,6 +663,38 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     if (rc) return rc;
     c->pend.active = true; c->pend.ep = ep; c->pend.h = h; c->pend.w = w; c->pend.identity = identity;
     c->pend.want_grad = want_grad; c->pend.full_aux = full_aux; c->pend.div_grad = div_grad; c->pend.host_asm = host_asm;
+    return EINCM_OK;
+}
+
+// The D2H copies of an evaluation whose results k_final left in HBM (d_outs, d_grad).  Enqueued right behind the kernels, or - with
+// eincm_set_device_results - only by eincm_finish_collect, after the caller has all-reduced the gradient in HBM.
+int enqueue_result_copies(eincm_ctx* c) {
+    const Geom& g = c->g;
+    const bool want_grad = c->pend.want_grad;
+    const size_t nth = (size_t)c->pend.h * c->pend.w * 2;
+    c->n_pieces = 0;
+    if (want_grad && (size_t)g.B * nth >= ((size_t)1 << 17)) {
+        // a dense gradient (4.9 MB at 480x640): in pieces, an event behind each, so that eval_end_collect hands piece k over
+        // (copy + finite scan on the host) while piece k + 1 is still crossing PCIe
+        HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal), hipMemcpyDeviceToHost, c->stream));
+        const size_t total = (size_t)g.B * nth;
+        c->piece_len = (total + eincm_ctx::GRAD_PIECES - 1) / eincm_ctx::GRAD_PIECES;
+        for (int k = 0; k < eincm_ctx::GRAD_PIECES; ++k) {
+            const size_t off = (size_t)k * c->piece_len;
+            if (off >= total) break;
+            const size_t n = std::min(c->piece_len, total - off);
+            HIPCHK(c, hipMemcpyAsync(c->h_grad + off, c->d_grad + off, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipEventRecord(c->ev_piece[k], c->stream));
+            c->n_pieces = k + 1;
+        }
+    } else if (want_grad && g.B == c->maxB) {      // outs and grad are contiguous: one copy
+        HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal) + (size_t)g.B * nth * sizeof(double),
+                                 hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal), hipMemcpyDeviceToHost, c->stream));
+        if (want_grad)
+            HIPCHK(c, hipMemcpyAsync(c->h_grad, c->d_grad, (size_t)g.B * nth * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
     return EINCM_OK;
 }
 
@@ -686,7 +720,7 @@ int eval_end_launch(eincm_ctx* c) {
     static const bool compose_env = getenv("EINCM_COMPOSE") != nullptr;
     const bool compose = want_grad && !div_grad && compose_env;
     const bool g2_from_imgrad = !compose && want_grad && ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG;
-    const bool zero_copy_out = !identity && (size_t)g.B * nth <= ZERO_COPY_MAX;
+    const bool zero_copy_out = !c->device_results && !identity && (size_t)g.B * nth <= ZERO_COPY_MAX;
     const bool stream_stats = host_asm || (g2_from_imgrad && g.ntiles >= NSPART);
     const int n_imwg = (g.nig + IG_NT / 64 - 1) / (IG_NT / 64);
     unsigned* gmax_buf = compose ? c->d_gbound : c->d_gmax;
@@ -820,30 +854,8 @@ int eval_end_launch(eincm_ctx* c) {
     if (want_grad) { c->last_composed = compose; c->last_ep = ep; c->last_g = g; }
     HIPCHK(c, hipGetLastError());
     c->n_pieces = 0;
-    if (zero_copy_out || host_asm) {
-        // nothing to copy
-    } else if (want_grad && (size_t)g.B * nth >= ((size_t)1 << 17)) {
-        // a dense gradient (4.9 MB at 480x640): in pieces, an event behind each, so that eval_end_collect hands piece k over
-        // (copy + finite scan on the host) while piece k + 1 is still crossing PCIe
-        HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal), hipMemcpyDeviceToHost, c->stream));
-        const size_t total = (size_t)g.B * nth;
-        c->piece_len = (total + eincm_ctx::GRAD_PIECES - 1) / eincm_ctx::GRAD_PIECES;
-        for (int k = 0; k < eincm_ctx::GRAD_PIECES; ++k) {
-            const size_t off = (size_t)k * c->piece_len;
-            if (off >= total) break;
-            const size_t n = std::min(c->piece_len, total - off);
-            HIPCHK(c, hipMemcpyAsync(c->h_grad + off, c->d_grad + off, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipEventRecord(c->ev_piece[k], c->stream));
-            c->n_pieces = k + 1;
-        }
-    } else if (want_grad && g.B == c->maxB) {      // outs and grad are contiguous: one copy
-        HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal) + (size_t)g.B * nth * sizeof(double),
-                                 hipMemcpyDeviceToHost, c->stream));
-    } else {
-        HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal), hipMemcpyDeviceToHost, c->stream));
-        if (want_grad)
-            HIPCHK(c, hipMemcpyAsync(c->h_grad, c->d_grad, (size_t)g.B * nth * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    }
+    c->pend.copy_mode = (zero_copy_out || host_asm) ? 0 : 1;
+    if (c->pend.copy_mode && !c->device_results) { const int rcc = enqueue_result_copies(c); if (rcc) return rcc; c->pend.copy_mode = 0; }
     if (timing && c->ring_size == 1) { (void)hipEventRecord(c->ev[c->ring_cur][EINCM_N_STAGES][1], c->stream); c->ev_used[c->ring_cur][EINCM_N_STAGES] = true; }
     c->pend.launched = true;
     c->acc_dirty = false;          // every accumulator this evaluation touched has been consumed (and cleared) by the kernels above
@@ -911,6 +923,7 @@ int eval_end_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) 
     const size_t nth = (size_t)c->pend.h * c->pend.w * 2;
     // The stream is drained before ANY return: the kernels in flight read the pinned theta staging buffer and write the pinned
     // result block, so the context must not look idle (and accept the next theta) while they run.
+    if (c->pend.copy_mode) { const int rcc = enqueue_result_copies(c); c->pend.copy_mode = 0; if (rcc) { (void)hipStreamSynchronize(c->stream); c->pend.active = false; c->pend.launched = false; return rcc; } }
     bool piece_bad = false;
     if (c->n_pieces > 0 && want_grad && grad) {
         const size_t total = (size_t)g.B * nth;
@@ -1621,6 +1634,39 @@ int eincm_finish_loss_grad(eincm_ctx* c, double* value, double* grad, eincm_aux*
     if (c->constants_pending) return fail(c, EINCM_ERR_STATE, "window constants pending (eincm_finish_constants)");
     HIPCHK(c, hipSetDevice(c->device));
     return eval_end(c, value, grad, aux);
+}
+
+int eincm_set_device_results(eincm_ctx* c, int on) {
+    if (!c) return EINCM_ERR_ARG;
+    if (c->pend.active) return fail(c, EINCM_ERR_STATE, "an evaluation is in flight");
+    c->device_results = on != 0;
+    return EINCM_OK;
+}
+
+int eincm_finish_launch(eincm_ctx* c) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!c->device_results) return fail(c, EINCM_ERR_STATE, "eincm_finish_launch needs eincm_set_device_results(ctx, 1)");
+    if (c->constants_pending) return fail(c, EINCM_ERR_STATE, "window constants pending (eincm_finish_constants)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = eval_end_launch(c);
+    if (rc) { (void)hipStreamSynchronize(c->stream); c->pend.active = false; c->pend.launched = false; return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // the gradient is complete in HBM: safe to reduce on any stream
+    return EINCM_OK;
+}
+
+int eincm_grad_device_ptr(eincm_ctx* c, void** dptr, int64_t* n_doubles) {
+    if (!c || !dptr || !n_doubles) return EINCM_ERR_ARG;
+    if (!c->pend.active || !c->pend.launched || !c->pend.want_grad) return fail(c, EINCM_ERR_STATE, "no launched gradient evaluation (eincm_finish_launch)");
+    *dptr = c->d_grad; *n_doubles = (int64_t)c->g.B * c->pend.h * c->pend.w * 2;
+    return EINCM_OK;
+}
+
+int eincm_finish_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!value) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (!c->pend.active || !c->pend.launched) return fail(c, EINCM_ERR_STATE, "eincm_finish_collect without eincm_finish_launch");
+    HIPCHK(c, hipSetDevice(c->device));
+    return eval_end_collect(c, value, grad, aux);
 }
 
 int eincm_finish_constants(eincm_ctx* c) {

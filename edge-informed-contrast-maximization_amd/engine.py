@@ -207,6 +207,26 @@ class Engine:
         auxl = [{k: getattr(a, k) for k, _ in L.Aux._fields_} for a in aux] if want_aux else None
         return value, grad, auxl
 
+    # -- the finishing half with the results kept in HBM (event-sharded mode over a GPU collective) ------------------
+    def set_device_results(self, on=True):
+        self._check(self._lib.eincm_set_device_results(self._ctx, 1 if on else 0))
+
+    def finish_launch(self):
+        self._check(self._lib.eincm_finish_launch(self._ctx))
+
+    def grad_tensor(self, theta_shape):
+        """torch view of the gradient of the launched evaluation in HBM, shaped like theta: all-reduce it in place."""
+        return self._device_view(self._lib.eincm_grad_device_ptr, '<f8', 8, tuple(theta_shape))
+
+    def finish_collect(self, theta_shape, want_grad=True, want_aux=False, allow_nonfinite=True):
+        value = np.empty(self.B, dtype=np.float64)
+        grad = np.empty(theta_shape, dtype=np.float64) if want_grad else None
+        aux = (L.Aux * self.B)() if want_aux else None
+        rc = self._lib.eincm_finish_collect(self._ctx, _dp(value), _dp(grad) if want_grad else None, aux)
+        self._check(rc, allow_nonfinite)
+        auxl = [{k: getattr(a, k) for k, _ in L.Aux._fields_} for a in aux] if want_aux else None
+        return value, grad, auxl
+
     def finish_constants(self):
         self._check(self._lib.eincm_finish_constants(self._ctx))
 

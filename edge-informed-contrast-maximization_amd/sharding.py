@@ -69,14 +69,47 @@ class ShardedEngine:
     (= RCCL over xGMI) reduces the engine's HBM buffer in place; 'gloo' (CPU rehearsal) bounces through host memory.
     """
 
-    def __init__(self, engine, rank=None, world_size=None):
+    def __init__(self, engine, rank=None, world_size=None, iwe_collective='all_reduce', device_results=None):
+        """iwe_collective: 'all_reduce' (the backend's default algorithm) or 'rs_ag' - reduce_scatter + all_gather of the int64
+        accumulator, the one-hop form SURVEY 8(e) argues for on point-to-point xGMI (a few MB per evaluation are latency-bound, a ring
+        pays 2 (n - 1) hops).  device_results: keep the gradient in HBM and all-reduce it there (default: whenever the backend is
+        'nccl').  NOTE: the 'nccl' (= RCCL) branches and 'rs_ag' have never run on hardware - the builder had no multi-GPU node - and
+        are covered only as far as a single process can (tests/test_gpu_sharded.py); gloo rehearsals take the host-bounced branches."""
         import torch.distributed as dist
+        if iwe_collective not in ('all_reduce', 'rs_ag'):
+            raise ValueError(f'iwe_collective {iwe_collective!r}: all_reduce or rs_ag')
         self.eng = engine
         self.dist = dist
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.rank = dist.get_rank() if self.on else 0
         self.world = dist.get_world_size() if self.on else 1
         self.gpu_collectives = self.on and dist.get_backend() == 'nccl'
+        self.iwe_collective = iwe_collective
+        self.device_results = self.gpu_collectives if device_results is None else bool(device_results)
+        if self.device_results:
+            self.eng.set_device_results(True)
+
+    def _allreduce_iwe_(self, t):
+        """Sum of the (B,R,H,W) int64 accumulator over the ranks, in place."""
+        import torch
+        D = self.dist
+        if self.on and self.gpu_collectives and self.iwe_collective == 'rs_ag':
+            flat = t.reshape(-1)
+            n = flat.numel()
+            per = -(-n // self.world)
+            if per * self.world != n:                       # pad to a multiple of the world size (a copy; the usual sizes divide)
+                buf = torch.zeros(per * self.world, dtype=flat.dtype, device=flat.device)
+                buf[:n] = flat
+            else:
+                buf = flat
+            mine = torch.empty(per, dtype=flat.dtype, device=flat.device)
+            D.reduce_scatter_tensor(mine, buf, op=D.ReduceOp.SUM)
+            D.all_gather_into_tensor(buf, mine)
+            if buf is not flat:
+                flat.copy_(buf[:n])
+            torch.cuda.current_stream().synchronize()
+            return
+        self._allreduce_(t, D.ReduceOp.SUM)
 
     def _allreduce_(self, t, op):
         import torch
@@ -97,7 +130,7 @@ class ShardedEngine:
         self.eng.set_windows(local_windows, defer_constants=True)
         self._allreduce_(self.eng.mask_tensor(), D.ReduceOp.MAX)          # TV needs the global event mask
         self.eng.forward_iwe(None, None)                                   # theta = 0: partial IUE of this shard
-        self._allreduce_(self.eng.iwe_tensor(), D.ReduceOp.SUM)
+        self._allreduce_iwe_(self.eng.iwe_tensor())
         self.eng.finish_constants()
 
     def loss_grad(self, theta, params, want_grad=True):
@@ -111,14 +144,15 @@ class ShardedEngine:
             p = copy.copy(params)
             p.flags = params.flags | L.PF_NO_TV_GRAD
         shape = self.eng.forward_iwe(theta, p, want_grad=want_grad)
-        self._allreduce_(self.eng.iwe_tensor(), D.ReduceOp.SUM)
+        self._allreduce_iwe_(self.eng.iwe_tensor())
+        if self.device_results:
+            # the gradient stays in HBM: finish up to k_final, all-reduce the engine's own buffer in place, then one D2H copy
+            self.eng.finish_launch()
+            if want_grad and self.on:
+                self._allreduce_(self.eng.grad_tensor(shape), D.ReduceOp.SUM)
+            v, g, _ = self.eng.finish_collect(shape, want_grad=want_grad)
+            return v, g
         v, g, _ = self.eng.finish_loss_grad(shape, want_grad=want_grad)
-        if want_grad and self.on:
-            t = torch.from_numpy(g)
-            if self.gpu_collectives:
-                t = t.cuda()
-                D.all_reduce(t, op=D.ReduceOp.SUM)
-                g = t.cpu().numpy()
-            else:
-                D.all_reduce(t, op=D.ReduceOp.SUM)
+        if want_grad and self.on:                                           # host-side collective (gloo rehearsal)
+            D.all_reduce(torch.from_numpy(g), op=D.ReduceOp.SUM)
         return v, g

@@ -223,6 +223,16 @@ int eincm_get_host_profile(eincm_ctx* ctx, double* us /* EINCM_N_HOST_PHASES */,
  * its timed loop instead of calling eincm_get_timings inside it) */
 int eincm_get_timings_total(eincm_ctx* ctx, eincm_timings* sum, int64_t* n_evals, int reset);
 
+/* Event-sharded mode over a GPU collective (RCCL): keep the results of the finishing half in HBM so that the caller can all-reduce
+ * the gradient there, instead of bouncing it through the host.  eincm_set_device_results(ctx, 1) once; then per evaluation
+ *   eincm_forward_iwe -> [all-reduce the IWE accumulator] -> eincm_finish_launch (returns with the gradient complete in HBM)
+ *   -> [all-reduce eincm_grad_device_ptr's n_doubles doubles] -> eincm_finish_collect (copies value / gradient / aux to the host).
+ * 2-DoF evaluations run their scalar assembly on the GPU again in this mode (k_final), so that the gradient exists in HBM. */
+int eincm_set_device_results(eincm_ctx* ctx, int on);
+int eincm_finish_launch(eincm_ctx* ctx);
+int eincm_grad_device_ptr(eincm_ctx* ctx, void** dptr, int64_t* n_doubles);
+int eincm_finish_collect(eincm_ctx* ctx, double* value, double* grad, eincm_aux* aux);
+
 /* Event-sharded evaluation: the events of the SAME windows are split over several contexts (one per GPU);
  * edges and edge_ts are replicated.  The IWE is additive over events (src/utils/event_utils.py:59 is a pure sum), so
  *   every shard:  eincm_forward_iwe(theta)            k_theta + k_splat on its own events; returns stream-synchronised

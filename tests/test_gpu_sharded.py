@@ -76,6 +76,35 @@ def test_world1_sharded_engine_equals_engine(built_lib):
             assert np.abs(g2 - g1).max() <= 2e-5 * np.abs(g1).max()
 
 
+def test_device_resident_finishing_half(built_lib):
+    """The RCCL form of the sharded evaluation keeps the gradient in HBM (eincm_set_device_results / finish_launch / grad_tensor /
+    finish_collect) so that it can be all-reduced there.  Without a multi-GPU node the collective itself cannot run; what a single
+    process can check: the split finishing half gives the results of the plain one (2-DoF theta included, whose scalar assembly moves
+    back to the GPU in this mode), and the tensor handed to the collective IS the gradient."""
+    import torch
+    engine = importlib.import_module('edge-informed-contrast-maximization_amd.engine')
+    sh = importlib.import_module('edge-informed-contrast-maximization_amd.sharding')
+    win, thetas = _inputs()
+    a = (win['xs'], win['ys'], win['ts'], win['edges'], win['edge_ts'])
+    with engine.Engine((H, W), N, max_refs=R) as e1, engine.Engine((H, W), N, max_refs=R) as e2:
+        e1.set_window(*a)
+        se = sh.ShardedEngine(e2, device_results=True)
+        se.set_windows([a])
+        for th, (hw, gamma, lvl) in zip(thetas, CASES):
+            p = engine.make_params(20.0, 35.0, gamma, 0.0, lvl)
+            v1, g1, _ = e1.loss_grad(th, p)
+            v2, g2 = se.loss_grad(th, p)
+            assert v2[0] == pytest.approx(v1[0], rel=2e-6)
+            assert np.abs(g2 - g1).max() <= 2e-5 * np.abs(g1).max()
+            shape = e2.forward_iwe(th, p)
+            e2.finish_launch()
+            t = e2.grad_tensor(shape)
+            assert t.is_cuda and t.dtype == torch.float64 and tuple(t.shape) == tuple(shape)
+            on_device = t.cpu().numpy().copy()
+            v3, g3, _ = e2.finish_collect(shape)
+            assert np.array_equal(on_device, g3) and np.array_equal(g3, g2) and v3[0] == v2[0]
+
+
 @pytest.mark.timeout(300)
 def test_two_ranks_split_events_match_unsharded(built_lib):
     from oracle import eincm_oracle as O
