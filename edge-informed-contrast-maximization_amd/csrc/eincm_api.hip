@@ -105,6 +105,7 @@ struct eincm_ctx {
     unsigned* d_amax = nullptr;    // (B,R,pstride) max |A| per k_imstat workgroup (float bits)
     unsigned* d_gbound = nullptr;  // (B,R) bound of max |dL/dIWE| per image from k_imstat's tail (float bits): what gmax is when gmax_n == R
     unsigned* d_ticket = nullptr;  // (B,R) arrival counters of k_imstat, zero between launches
+    unsigned* d_gticket = nullptr; // (B) arrival counters of the gather's tail (theta grids), zero between launches
     ImgCoef* d_coef = nullptr;     // (B,R) what the gather composes dL/dIWE with
     float* d_Gimg = nullptr;       // (B,R,H,W) dL/dIWE materialised for eincm_get_image_grad after a composed evaluation (allocated on demand)
     bool last_composed = false;    // the last gradient evaluation left A in d_G (the gather composed dL/dIWE on the fly)
@@ -278,7 +279,7 @@ void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(c->d_xy); F(c->d_t); F(c->d_xy_g); F(c->d_t_g); F(c->d_items); F(c->d_items_s); F(c->d_items_2); F(c->d_order_2); F(c->d_win_item0_2); F(c->d_order); F(c->d_order_s); F(c->d_wins); F(c->d_wins_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
     F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_itembase_s); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_acc); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
-    F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax); F(c->d_cntmax); F(c->d_amax); F(c->d_gbound); F(c->d_ticket); F(c->d_coef); F(c->d_Gimg);
+    F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax); F(c->d_cntmax); F(c->d_amax); F(c->d_gbound); F(c->d_ticket); F(c->d_gticket); F(c->d_coef); F(c->d_Gimg);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
     F(c->d_divparts); F(c->d_g2parts); F(c->d_gdiv); F(c->d_dgparts); F(c->d_tvparts); F(c->d_wc); F(c->d_outs); c->d_grad = nullptr; F(c->d_gth); F(c->d_AH); F(c->d_AW);
     F(c->d_rowtap); F(c->d_coltap); F(c->d_tilerng);
@@ -654,10 +655,15 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     // 2-DoF theta with nothing but the contrast and correlation terms (every level above 0 of the reference's pyramid at its first
     // level, and the bench workload): the scalar assembly and the sum of the gather's per-workgroup partials run on the host
     static const bool no_host_asm = getenv("EINCM_NO_HOST_ASM") != nullptr;
-    const bool host_asm = want_grad && !identity && h == 1 && w == 1 && !ep.want_div && !ep.want_tv && !full_aux && !no_host_asm && !c->device_results;
+    const bool grid_tail = !(h == 1 && w == 1) && c->proj_in_gather && c->itembase_valid && (size_t)g.B * nth <= ZERO_COPY_MAX;
+    const bool host_asm = want_grad && !identity && (h == 1 && w == 1 || grid_tail) && !ep.want_div && !ep.want_tv && !full_aux && !no_host_asm && !c->device_results;
     if (host_asm) {
         c->theta_nan.assign((size_t)g.B, 0);
-        for (int b = 0; b < g.B; ++b) c->theta_nan[b] = !(std::isfinite(theta_host[2 * b]) && std::isfinite(theta_host[2 * b + 1]));
+        for (int b = 0; b < g.B; ++b) {
+            bool bad = false;
+            for (size_t i = 0; i < nth; ++i) bad = bad || !std::isfinite(theta_host[(size_t)b * nth + i]);
+            c->theta_nan[b] = bad;
+        }
     }
     int rc = launch_forward(c, h, w, identity, ep.want_tv != 0, theta_host, host_asm);
     if (rc) return rc;
@@ -810,7 +816,8 @@ int eval_end_launch(eincm_ctx* c) {
                     direct11 ? 1 : 0, host_asm ? c->h_g11 : c->d_g11, c->d_wc, gmax_buf, direct11 ? THETA_CONST : THETA_TILE, order_g, \
                     c->pend.use_arg ? 1 : 0, c->pend.theta_dev, c->pend.targ, \
                     ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG ? 1 : 0, c->d_edges, c->d_iwe, c->d_coef, c->d_acc, 1, nparts, \
-                    h, w, c->d_AH, c->d_AW, c->d_tilerng, c->d_gth, (int)c->coarse_cap
+                    h, w, c->d_AH, c->d_AW, c->d_tilerng, c->d_gth, (int)c->coarse_cap, \
+                    (host_asm && proj) ? 1 : 0, c->d_gticket, c->d_win_item0, c->h_grad
 #define GATHER_TILE(WIDE_, COMPOSE_, PROJ_) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, WIDE_, NT_TILE, COMPOSE_, PROJ_>, GATHER_ARGS(NT_TILE))
                 if (direct11) {
                     if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 1, 0>, GATHER_ARGS(NT));
@@ -906,12 +913,17 @@ void host_assemble(eincm_ctx* c) {
         o.tv = (ep.cur_pyr_lvl <= 0) ? NAN : 0.0;
         o.value = val; o.tv_scale = 0.0;
         o.nonfinite = std::isfinite(val) ? 0.0 : 1.0;
-        const int lo = c->h_win_item0_2[b], hi = c->h_win_item0_2[b + 1];
-        const double* p = c->h_g11 + (size_t)lo * c->g11_per_item * 2;
-        const size_t n = (size_t)(hi - lo) * c->g11_per_item;
-        double sx = 0.0, sy = 0.0;
-        for (size_t k = 0; k < n; ++k) { sx += p[2 * k]; sy += p[2 * k + 1]; }
-        c->h_grad[(size_t)b * 2] = sx; c->h_grad[(size_t)b * 2 + 1] = sy;
+        if (c->pend.h == 1 && c->pend.w == 1) {              // 2-DoF: the gather's per-workgroup partials, added in index order
+            const int lo = c->h_win_item0_2[b], hi = c->h_win_item0_2[b + 1];
+            const double* p = c->h_g11 + (size_t)lo * c->g11_per_item * 2;
+            const size_t n = (size_t)(hi - lo) * c->g11_per_item;
+            double sx = 0.0, sy = 0.0;
+            for (size_t k = 0; k < n; ++k) { sx += p[2 * k]; sy += p[2 * k + 1]; }
+            c->h_grad[(size_t)b * 2] = sx; c->h_grad[(size_t)b * 2 + 1] = sy;
+        } else if (c->win_events[b] == 0) {                  // theta grid: the gather's tail wrote dL/dtheta, unless the window has no workgroup
+            const size_t n = (size_t)c->pend.h * c->pend.w * 2;
+            for (size_t i = 0; i < n; ++i) c->h_grad[(size_t)b * n + i] = 0.0;
+        }
     }
 }
 
@@ -1166,6 +1178,8 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_ticket, B * R));
     TRY(hipMemset(c->d_ticket, 0, B * R * sizeof(unsigned)));
     TRY(dalloc(&c->d_coef, B * R));
+    TRY(dalloc(&c->d_gticket, B));
+    TRY(hipMemset(c->d_gticket, 0, B * sizeof(unsigned)));
     TRY(dalloc(&c->d_divparts, B * R * ntiles));
     TRY(dalloc(&c->d_g2parts, B * R * nig));
     TRY(dalloc(&c->d_tvparts, B * ntiles * 3));

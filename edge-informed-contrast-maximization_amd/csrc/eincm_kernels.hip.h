@@ -1593,7 +1593,10 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         // cells itself, dL/dtheta[i,j] += sum_{y,x} AH[y,i] AW[x,j] dL/dTheta[y,x] (reverse of theta_utils.py:25-35), instead of
         // flushing them into the dL/dTheta image for k_project: 2 x 32 x 32 global atomics per workgroup become <= 2 ni nj
         int h, int w, const double* __restrict__ AH, const double* __restrict__ AW, const TileRange* __restrict__ tilerng,
-        long long* __restrict__ gth_main, int gth_cap)
+        long long* __restrict__ gth_main, int gth_cap,
+        // tail (PROJ only, tail != 0): the workgroup of a window that finishes LAST turns the window's i64 cell sums into dL/dtheta and
+        // writes it where the host reads it - what k_final did in a launch of its own (7-8 us of a 65 us evaluation)
+        int tail, unsigned* __restrict__ ticket, const int32_t* __restrict__ win_item0, double* __restrict__ grad_out)
 {
     const int part = blockIdx.y;
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
@@ -1819,6 +1822,28 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
             unsigned long long* o = out + ((size_t)(tr.ilo + ii) * w + (tr.jlo + jj)) * 2;
             if (ax != 0.0) atomicAdd(o, (unsigned long long)fix64_wide(ax));
             if (ay != 0.0) atomicAdd(o + 1, (unsigned long long)fix64_wide(ay));
+        }
+        if (!tail) return;
+        // Every cell atomic of this workgroup has been performed (vmcnt counts them until they are) before its ticket is drawn, and
+        // integer atomics of all workgroups meet at one coherence point, so the workgroup that draws the last ticket of its window
+        // sees every contribution when it exchanges the cells for zero (which also leaves them clear for the next evaluation).
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int n_it = ((it.win + 1 < g.B) ? win_item0[it.win + 1] : n_items) - win_item0[it.win];
+            const unsigned old = __hip_atomic_fetch_add(ticket + it.win, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = old == (unsigned)(n_it * g.R) - 1u;
+            if (last) __hip_atomic_store(ticket + it.win, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = last ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const double inv = ldexp(1.0, -grad_shift(wc[it.win], gmd, g.R));
+        const int ncell = h * w * 2;
+        for (int i = threadIdx.x; i < ncell; i += NTH) {
+            const long long q = (long long)atomicExch(out + i, 0ull);
+            grad_out[(size_t)it.win * ncell + i] = (double)q * inv;
         }
         return;
     }
