@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): kernel trace + stats, then HBM PMC counters in their own passes.
 # Usage: tools/profile_round.sh <tag>      outputs under gpurun_out/prof_<tag>/
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
