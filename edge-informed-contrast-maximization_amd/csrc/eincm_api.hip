@@ -656,7 +656,7 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     // level, and the bench workload): the scalar assembly and the sum of the gather's per-workgroup partials run on the host
     static const bool no_host_asm = getenv("EINCM_NO_HOST_ASM") != nullptr;
     const bool grid_tail = !(h == 1 && w == 1) && c->proj_in_gather && c->itembase_valid && (size_t)g.B * nth <= ZERO_COPY_MAX;
-    const bool host_asm = want_grad && !identity && (h == 1 && w == 1 || grid_tail) && !ep.want_div && !ep.want_tv && !full_aux && !no_host_asm && !c->device_results;
+    const bool host_asm = want_grad && !identity && ((h == 1 && w == 1) || grid_tail) && !ep.want_div && !ep.want_tv && !full_aux && !no_host_asm && !c->device_results;
     if (host_asm) {
         c->theta_nan.assign((size_t)g.B, 0);
         for (int b = 0; b < g.B; ++b) {

@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define EINCM_ABI_VERSION 3   /* 2: eincm_iwe_device_ptr hands out the u64 fixed-point accumulator of the IWE stack; 3: eincm_set_timed_kernels, eincm_set_windows_ptrs */
+#define EINCM_ABI_VERSION 4   /* 2: eincm_iwe_device_ptr hands out the u64 fixed-point accumulator of the IWE stack; 3: eincm_set_timed_kernels, eincm_set_windows_ptrs;
+                                * 4: eincm_loss_grad_masked, eincm_set_device_results / eincm_finish_launch / eincm_grad_device_ptr / eincm_finish_collect, eincm_get_host_profile */
 
 #define EINCM_OK               0
 #define EINCM_ERR_ARG         -1   /* bad argument (shape, null pointer, out-of-range event coordinate) */
