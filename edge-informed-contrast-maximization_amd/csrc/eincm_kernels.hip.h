@@ -1043,8 +1043,9 @@ __global__ __launch_bounds__(IG_NT) void k_imgrad(Geom g, EvalParams ep,
         float* __restrict__ G,
         unsigned* __restrict__ gmax,           // (B,R,nig): this strip's max |G| as float bits: fixes the fixed-point scale of the
                                                // gradient accumulators (gmax_of, grad_shift)
-        double* __restrict__ imgscal_out)      // (B,R,IMGSCAL_N) or nullptr: the reduced image scalars, written once per image (in pinned host
+        double* __restrict__ imgscal_out,      // (B,R,IMGSCAL_N) or nullptr: the reduced image scalars, written once per image (in pinned host
                                                // memory on the path whose scalar assembly runs on the host: host_assemble)
+        int g2_per_wg)                         // g2parts holds one partial per workgroup, (B,R,gridDim.x), instead of one per strip
 {
     __shared__ double sc[10];
     const bool use_div = (ep.delta != 0.0);
@@ -1103,9 +1104,10 @@ __global__ __launch_bounds__(IG_NT) void k_imgrad(Geom g, EvalParams ep,
         }
     }
     __syncthreads();
-    if (strip >= g.nig) return;                              // wave-uniform
+    const bool live = strip < g.nig;                         // wave-uniform; a dead wave (last workgroup of an image) runs along on clamped
+                                                             // addresses and owns nothing, so that the workgroup can meet at the end
     const bool col_in = (x >= 0 && x < g.W);
-    const bool own = col_in && lane >= 2 && lane < 2 + IG_COLS;
+    const bool own = live && col_in && lane >= 2 && lane < 2 + IG_COLS;
     const int yend = min(cy0 + IG_ROWS, g.H);                // own rows [cy0, yend)
     const bool gradmag = (ep.contrast_kind == 0);
     const double m = sc[0], M = sc[1], invD = sc[9], k_c = sc[3], k_n = sc[4], k_m = sc[5], k_M = sc[6], meanI = sc[7], k_d = sc[8];
@@ -1154,9 +1156,19 @@ __global__ __launch_bounds__(IG_NT) void k_imgrad(Geom g, EvalParams ep,
     const double g2 = wave_sum((double)g2f);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) gm = max(gm, (unsigned)__shfl_down((int)gm, o, 64));
-    if (lane == 0) {
-        g2parts[((size_t)b * g.R + r) * g.nig + strip] = g2;
+    if (lane == 0 && live) {
+        if (!g2_per_wg) g2parts[((size_t)b * g.R + r) * g.nig + strip] = g2;
         gmax[((size_t)b * g.R + r) * g.nig + strip] = gm;
+    }
+    if (g2_per_wg) {            // host-assembled evaluations: one contrast-energy partial per workgroup (a quarter of the bytes the host reads back)
+        __shared__ double g2w[IG_NT / 64];
+        if (lane == 0) g2w[threadIdx.x >> 6] = live ? g2 : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = g2w[0];
+            for (int i = 1; i < IG_NT / 64; ++i) t += g2w[i];
+            g2parts[((size_t)b * g.R + r) * gridDim.x + blockIdx.x] = t;
+        }
     }
 }
 
