@@ -146,6 +146,7 @@ struct eincm_ctx {
     double* h_g11 = nullptr;       // (max_items + NXCD, R, 2) per-workgroup partials of dL/dtheta (k_gather)
     double* h_g2 = nullptr;        // (B,R,nig) contrast energy per k_imgrad strip
     double* h_img = nullptr;       // (B,R,IMGSCAL_N) reduced image scalars (k_imgrad)
+    double* h_tvparts = nullptr;   // (B,ntiles,3) k_tv's per-tile partials (host-assembled evaluations with the TV term)
 
     // timing.  EINCM_CF_TIMING_DOMINANT keeps a ring of event sets and reads them out later (eincm_get_timings*): asking HIP for
     // elapsed times after every evaluation cost the caller ~15 us per evaluation, which a throughput measurement should not pay.
@@ -174,6 +175,7 @@ struct eincm_ctx {
     struct { bool active = false; bool launched = false; EvalParams ep{}; int h = 0, w = 0; bool identity = false, want_grad = false, full_aux = false, div_grad = false;
              bool host_asm = false;                 // scalar assembly and the 2-DoF gradient sum on the host (see h_g11)
              bool composed = false;                 // k_imstat + composing gather (host_assemble: the contrast energy rides in h_img)
+             bool tv_projected = false;             // k_tv projected its gradient onto the theta cells itself (no k_project for it)
              int copy_mode = 0;                     // 1: the D2H copies of the results are still to be enqueued (device_results)
              bool use_arg = false; const double* theta_dev = nullptr; ThetaArg targ{};      // where the event kernels find a 2-DoF theta
              } pend;
@@ -285,7 +287,7 @@ void free_all(eincm_ctx* c) {
     F(c->d_rowtap); F(c->d_coltap); F(c->d_tilerng);
     for (DevBuf* b : {&c->e_u8, &c->e_g, &c->e_sq, &c->e_misc, &c->e_a, &c->e_b, &c->e_kern, &c->e_out}) { F(b->p); b->bytes = 0; }
     auto FH = [](auto*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } };
-    FH(c->h_theta); FH(c->h_outs); c->h_grad = nullptr; FH(c->h_wc); FH(c->h_g11); FH(c->h_g2); FH(c->h_img);
+    FH(c->h_theta); FH(c->h_outs); c->h_grad = nullptr; FH(c->h_wc); FH(c->h_g11); FH(c->h_g2); FH(c->h_img); FH(c->h_tvparts);
     if (c->have_events) {
         for (int k = 0; k < eincm_ctx::EV_RING; ++k)
             for (int i = 0; i <= EINCM_N_STAGES; ++i)
@@ -656,7 +658,10 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     // level, and the bench workload): the scalar assembly and the sum of the gather's per-workgroup partials run on the host
     static const bool no_host_asm = getenv("EINCM_NO_HOST_ASM") != nullptr;
     const bool grid_tail = !(h == 1 && w == 1) && c->proj_in_gather && c->itembase_valid && (size_t)g.B * nth <= ZERO_COPY_MAX;
-    const bool host_asm = want_grad && !identity && ((h == 1 && w == 1) || grid_tail) && !ep.want_div && !ep.want_tv && !full_aux && !no_host_asm && !c->device_results;
+    // (the TV term rides along on a theta grid: k_tv projects its own gradient and the gather's tail combines it; a 2-DoF theta with
+    // TV - no level of the reference's pyramid - keeps k_final)
+    const bool host_asm = want_grad && !identity && (((h == 1 && w == 1) && !ep.want_tv) || grid_tail) && !ep.want_div && !full_aux && !no_host_asm &&
+                          !c->device_results;
     if (host_asm) {
         c->theta_nan.assign((size_t)g.B, 0);
         for (int b = 0; b < g.B; ++b) {
@@ -763,8 +768,14 @@ int eval_end_launch(eincm_ctx* c) {
     }
     if (ep.want_tv) {
         StageTimer t(c, EINCM_STAGE_TV, true);
-        launch_timed(c, EINCM_STAGE_TV, k_tv, dim3(g.ntiles, g.B), dim3(NT), 0, g, c->d_Theta, c->d_mask, c->d_tvg,
-                           c->d_tvparts, full_aux ? 1 : 0);
+        // theta grids coarse enough for it: k_tv projects its tile's gradient onto the theta cells itself (no image, no k_project)
+        const bool tv_proj = ep.use_tv_grad && !identity && !(h == 1 && w == 1) && c->proj_in_gather;
+#define TV_ARGS dim3(g.ntiles, g.B), dim3(NT), 0, g, c->d_Theta, c->d_mask, c->d_tvg, c->d_tvparts, full_aux ? 1 : 0, \
+                h, w, c->d_AH, c->d_AW, c->d_tilerng, c->d_gth + (size_t)c->maxB * c->coarse_cap, (int)c->coarse_cap, host_asm ? c->h_tvparts : nullptr
+        if (tv_proj) launch_timed(c, EINCM_STAGE_TV, k_tv<1>, TV_ARGS);
+        else         launch_timed(c, EINCM_STAGE_TV, k_tv<0>, TV_ARGS);
+#undef TV_ARGS
+        c->pend.tv_projected = tv_proj;
     }
     const bool direct11 = want_grad && !identity && h == 1 && w == 1;
     const bool proj = want_grad && !identity && !direct11 && c->proj_in_gather;      // k_gather projects its tile's sums itself
@@ -817,7 +828,8 @@ int eval_end_launch(eincm_ctx* c) {
                     c->pend.use_arg ? 1 : 0, c->pend.theta_dev, c->pend.targ, \
                     ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG ? 1 : 0, c->d_edges, c->d_iwe, c->d_coef, c->d_acc, 1, nparts, \
                     h, w, c->d_AH, c->d_AW, c->d_tilerng, c->d_gth, (int)c->coarse_cap, \
-                    (host_asm && proj) ? 1 : 0, c->d_gticket, c->d_win_item0, c->h_grad
+                    (host_asm && proj) ? 1 : 0, c->d_gticket, c->d_win_item0, c->h_grad, \
+                    (host_asm && proj && ep.use_tv_grad) ? ep.gamma : 0.0, c->d_tvparts, c->d_gth + (size_t)c->maxB * c->coarse_cap
 #define GATHER_TILE(WIDE_, COMPOSE_, PROJ_) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, WIDE_, NT_TILE, COMPOSE_, PROJ_>, GATHER_ARGS(NT_TILE))
                 if (direct11) {
                     if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 1, 0>, GATHER_ARGS(NT));
@@ -838,7 +850,8 @@ int eval_end_launch(eincm_ctx* c) {
         // 2-DoF theta: k_gather left per-workgroup partials of the event gradient for k_final; only the TV image needs projecting.
         // (a theta grid coarse enough for k_gather's own projection leaves only the TV image to k_project)
         const bool events_projected = direct11 || proj;
-        const int nsrc = (events_projected ? 0 : 1) + (ep.use_tv_grad ? 1 : 0);
+        const bool tv_needs_project = ep.use_tv_grad && !(ep.want_tv && c->pend.tv_projected);
+        const int nsrc = (events_projected ? 0 : 1) + (tv_needs_project ? 1 : 0);
         if (!identity && nsrc > 0) {
             StageTimer t(c, EINCM_STAGE_PROJECT, true);
             launch_timed(c, EINCM_STAGE_PROJECT, k_project, dim3(g.ntiles, g.B, nsrc), dim3(NT), 0, g, h, w,
@@ -909,9 +922,16 @@ void host_assemble(eincm_ctx* c) {
         }
         const double mrc = sum_rel_con / Rd, mrr = sum_rel_corr / Rd;
         double val = ep.alpha * (-mrc) + ep.beta * (-mrr);
+        double tv = 0.0;
+        if (ep.want_tv) {                                    // regularizers.py:14-38 from k_tv's per-tile partials, losses.py:171
+            double a = 0.0, nz = 0.0;
+            for (int i = 0; i < g.ntiles; ++i) { a += c->h_tvparts[((size_t)b * g.ntiles + i) * 3]; nz += c->h_tvparts[((size_t)b * g.ntiles + i) * 3 + 1]; }
+            tv = a / (nz + EPSN);
+            if (ep.gamma != 0.0) val += ep.gamma * ((ep.cur_pyr_lvl <= 0) ? tv : 0.0);
+        }
         if (c->theta_nan[b]) val = NAN;             // a NaN anywhere in theta surfaces as a NaN loss, like in the reference
         o.mean_rel_contrast = mrc; o.mean_rel_corr = mrr; o.mean_rel_div = NAN;
-        o.tv = (ep.cur_pyr_lvl <= 0) ? NAN : 0.0;
+        o.tv = (ep.cur_pyr_lvl <= 0) ? (ep.want_tv ? tv : NAN) : 0.0;
         o.value = val; o.tv_scale = 0.0;
         o.nonfinite = std::isfinite(val) ? 0.0 : 1.0;
         if (c->pend.h == 1 && c->pend.w == 1) {              // 2-DoF: the gather's per-workgroup partials, added in index order
@@ -1212,6 +1232,7 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_g11), (size_t)(c->max_items + NXCD) * R * 2 * 4 * sizeof(double), hipHostMallocDefault));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_g2), B * R * nig * sizeof(double), hipHostMallocDefault));
     TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_img), B * R * IMGSCAL_N * sizeof(double), hipHostMallocDefault));
+    TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_tvparts), B * ntiles * 3 * sizeof(double), hipHostMallocDefault));
     c->have_events = true;
     for (int k = 0; k < eincm_ctx::GRAD_PIECES; ++k) TRY(hipEventCreateWithFlags(&c->ev_piece[k], hipEventDisableTiming));
     c->ring_size = (flags & EINCM_CF_TIMING_DOMINANT) && !(flags & EINCM_CF_TIMING) ? eincm_ctx::EV_RING : 1;

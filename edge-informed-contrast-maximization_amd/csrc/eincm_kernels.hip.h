@@ -1582,8 +1582,67 @@ __device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, cons
 // slots in index order).  Otherwise: per-pixel sums are accumulated in an LDS copy of the source tile as i64 fixed point
 // (ds_add_u64; scale grad_shift_pixel) and flushed with i64 global atomics.  Both are bit-reproducible.
 // ------------------------------------------------------------------------------------------------
+// |tvg| <= 2 * 32 per pixel and component (two adjoint Scharr stencils of +-1 images); times H*W pixels, times <= 4 for the weights
+__host__ __device__ __forceinline__ int tv_shift(int H, int W) {
+    int e = 0;
+    while ((double)(1ull << e) <= 256.0 * (double)H * (double)W) ++e;
+    return 61 - e;
+}
 constexpr int PG_MAXC = 6;        // coarse rows / columns under one 32x32 tile that k_gather's own projection handles (16x16 theta on 260x346: 4)
 struct TileRange { int ilo, ni, jlo, nj; };     // the coarse cells a tile's pixels have weight on (host: ensure_resample)
+
+// One 32x32 tile of a (H,W,2) image projected onto the theta cells, cells[i,j] += sum_{y,x} AH[y,i] AW[x,j] vals[y,x]  (the adjoint of
+// theta_utils.py:25-35 restricted to the tile), by the whole workgroup.  vals: the tile as double2 in LDS, already at the cells'
+// fixed-point scale, pixel (ly, lx) at (ly << 5) + (lx ^ ly) (the swizzle spreads the column walk of step A over the LDS banks);
+// written by the caller, who does NOT need to synchronise before the call.  scratch: LDS for the weights and the row results
+// (PROJ_SCRATCH_BYTES).  Separable and ordered: A) every (column half, tile row, coarse column) sums 16 products against A_W,
+// B) every cell sums the 32 row results against A_H - fp64 in a fixed order, ONE rounding per (workgroup, cell), then an i64 atomic:
+// the cell sums do not depend on the order of arrival.  tr.ni, tr.nj <= PG_MAXC.
+constexpr int PROJ_SCRATCH_BYTES = 2 * TS * PG_MAXC * 8 + 2 * TS * PG_MAXC * 16;
+template <int NTH>
+__device__ __forceinline__ void project_tile_to_cells(const Geom& g, int h, int w, const TileRange& tr, int x0, int y0,
+                                                      const double* __restrict__ AH, const double* __restrict__ AW,
+                                                      const double2* vals, void* scratch, unsigned long long* __restrict__ cells) {
+    const int ni = tr.ni, nj = tr.nj;
+    double* ahs = reinterpret_cast<double*>(scratch);               // (32, ni)
+    double* aws = ahs + TS * PG_MAXC;                                // (32, nj)
+    double2* st = reinterpret_cast<double2*>(aws + TS * PG_MAXC);    // (2, 32, nj) row results of the two column halves
+    for (int k = threadIdx.x; k < TS * ni; k += NTH) {
+        const int ly = k / ni, i = k - ly * ni;
+        ahs[k] = (y0 + ly < g.H) ? AH[(size_t)(y0 + ly) * h + tr.ilo + i] : 0.0;
+    }
+    for (int k = threadIdx.x; k < TS * nj; k += NTH) {
+        const int lx = k / nj, j = k - lx * nj;
+        aws[k] = (x0 + lx < g.W) ? AW[(size_t)(x0 + lx) * w + tr.jlo + j] : 0.0;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * TS * nj; k += NTH) {
+        const int q = k / (TS * nj), kk = k - q * (TS * nj);
+        const int ly = kk / nj, jj = kk - ly * nj;
+        double ax = 0.0, ay = 0.0;
+#pragma unroll 4                                             // (fully unrolled these loops cost k_gather 90 VGPRs: 8 -> 3 waves per SIMD)
+        for (int lx = 16 * q; lx < 16 * q + 16; ++lx) {
+            const double wgt = aws[lx * nj + jj];
+            const double2 v = vals[(ly << 5) + (lx ^ ly)];
+            ax += wgt * v.x; ay += wgt * v.y;
+        }
+        st[k] = make_double2(ax, ay);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ni * nj; k += NTH) {
+        const int ii = k / nj, jj = k - ii * nj;
+        double ax = 0.0, ay = 0.0;
+#pragma unroll 4
+        for (int ly = 0; ly < TS; ++ly) {
+            const double wgt = ahs[ly * ni + ii];
+            const double2 v0 = st[ly * nj + jj], v1 = st[TS * nj + ly * nj + jj];
+            ax += wgt * (v0.x + v1.x); ay += wgt * (v0.y + v1.y);
+        }
+        unsigned long long* o = cells + ((size_t)(tr.ilo + ii) * w + (tr.jlo + jj)) * 2;
+        if (ax != 0.0) atomicAdd(o, (unsigned long long)fix64_wide(ax));
+        if (ay != 0.0) atomicAdd(o + 1, (unsigned long long)fix64_wide(ay));
+    }
+}
 template <int TM, int WIDE, int NTH, int COMPOSE, int PROJ>      // NTH threads per workgroup: 256, or 512 where the LDS footprint allows only 3 workgroups per CU (THETA_TILE); TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
 __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WIDE: 61-bit fixed point per event (tiny windows, see grad_shift_pixel)
         const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
@@ -1608,7 +1667,8 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         long long* __restrict__ gth_main, int gth_cap,
         // tail (PROJ only, tail != 0): the workgroup of a window that finishes LAST turns the window's i64 cell sums into dL/dtheta and
         // writes it where the host reads it - what k_final did in a launch of its own (7-8 us of a 65 us evaluation)
-        int tail, unsigned* __restrict__ ticket, const int32_t* __restrict__ win_item0, double* __restrict__ grad_out)
+        int tail, unsigned* __restrict__ ticket, const int32_t* __restrict__ win_item0, double* __restrict__ grad_out,
+        double tv_gamma, const double* __restrict__ tvparts, long long* __restrict__ gth_tv)   // tail with the TV term (gamma != 0 at level 0)
 {
     const int part = blockIdx.y;
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
@@ -1781,25 +1841,10 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
     return;
 #endif
     if (PROJ) {
-        // Separable and ordered, like k_project's staged form: A) every (tile row, coarse column) sums its row against A_W, B) every
-        // cell sums the 32 row results against A_H; fp64 in a fixed order, ONE rounding per (workgroup, cell) into the i64 cell sums
-        // (scale grad_shift), integer atomics across workgroups: bit-reproducible.  The G window is dead by now: its LDS holds the weights.
+        // The tile's sums projected onto the theta cells (project_tile_to_cells); the G window is dead by now: its LDS holds the weights.
         const TileRange tr = tilerng[it.tile];
-        const int ni = tr.ni, nj = tr.nj;
-        double* ahs = reinterpret_cast<double*>(lds);                    // (32, ni)
-        double* aws = ahs + TS * PG_MAXC;                                // (32, nj)
-        double2* st = reinterpret_cast<double2*>(aws + TS * PG_MAXC);    // (2, 32, nj) row results of the two column halves
-        static_assert((2 * TS * PG_MAXC * 8 + 2 * TS * PG_MAXC * 16) <= WIN_CAP_DEFAULT * 4, "the projection's scratch fits the smallest G window");
-        for (int k = threadIdx.x; k < TS * ni; k += NTH) {
-            const int ly = k / ni, i = k - ly * ni;
-            ahs[k] = (y0 + ly < g.H) ? AH[(size_t)(y0 + ly) * h + tr.ilo + i] : 0.0;
-        }
-        for (int k = threadIdx.x; k < TS * nj; k += NTH) {
-            const int lx = k / nj, j = k - lx * nj;
-            aws[k] = (x0 + lx < g.W) ? AW[(size_t)(x0 + lx) * w + tr.jlo + j] : 0.0;
-        }
-        // the sums as doubles at the cell scale, into the (dead) Theta tile: one conversion per pixel by all threads instead of one per
-        // product; pixel (ly, lx) sits at ly * 32 + (lx ^ ly), so that the column walk of step A spreads over the LDS banks
+        static_assert(PROJ_SCRATCH_BYTES <= WIN_CAP_DEFAULT * 4, "the projection's scratch fits the smallest G window");
+        // the sums as doubles at the cell scale, into the (dead) Theta tile: one conversion per pixel by all threads
         const double gmd = gm_used;                                      // the same value k_final derives its scale from (a float read back)
         const double scale = ldexp(1.0, grad_shift(wc[it.win], gmd, g.R) - grad_shift_pixel(wc[it.win], gmd, g.R, WIDE != 0));
         for (int p = threadIdx.x; p < TS * TS; p += NTH) {
@@ -1807,34 +1852,8 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
             const long long vx = (long long)accum[p * 2], vy = (long long)accum[p * 2 + 1];       // exact conversions for |.| < 2^53 (always, unless WIDE)
             thtile[(ly << 5) + (lx ^ ly)] = make_double2((double)vx * scale, (double)vy * scale);
         }
-        __syncthreads();
-        for (int k = threadIdx.x; k < 2 * TS * nj; k += NTH) {           // A) (column half, tile row, coarse column): 16 products each
-            const int q = k / (TS * nj), kk = k - q * (TS * nj);
-            const int ly = kk / nj, jj = kk - ly * nj;
-            double ax = 0.0, ay = 0.0;
-#pragma unroll 4                                             // (fully unrolled the loops of this block cost the kernel 90 VGPRs: 8 -> 3 waves per SIMD)
-            for (int lx = 16 * q; lx < 16 * q + 16; ++lx) {
-                const double wgt = aws[lx * nj + jj];
-                const double2 v = thtile[(ly << 5) + (lx ^ ly)];
-                ax += wgt * v.x; ay += wgt * v.y;
-            }
-            st[k] = make_double2(ax, ay);
-        }
-        __syncthreads();
         unsigned long long* __restrict__ out = reinterpret_cast<unsigned long long*>(gth_main) + (size_t)it.win * gth_cap;
-        for (int k = threadIdx.x; k < ni * nj; k += NTH) {               // B) every cell: the 32 row results against A_H
-            const int ii = k / nj, jj = k - ii * nj;
-            double ax = 0.0, ay = 0.0;
-#pragma unroll 4
-            for (int ly = 0; ly < TS; ++ly) {
-                const double wgt = ahs[ly * ni + ii];
-                const double2 v0 = st[ly * nj + jj], v1 = st[TS * nj + ly * nj + jj];
-                ax += wgt * (v0.x + v1.x); ay += wgt * (v0.y + v1.y);
-            }
-            unsigned long long* o = out + ((size_t)(tr.ilo + ii) * w + (tr.jlo + jj)) * 2;
-            if (ax != 0.0) atomicAdd(o, (unsigned long long)fix64_wide(ax));
-            if (ay != 0.0) atomicAdd(o + 1, (unsigned long long)fix64_wide(ay));
-        }
+        project_tile_to_cells<NTH>(g, h, w, tr, x0, y0, AH, AW, thtile, lds, out);
         if (!tail) return;
         // Every cell atomic of this workgroup has been performed (vmcnt counts them until they are) before its ticket is drawn, and
         // integer atomics of all workgroups meet at one coherence point, so the workgroup that draws the last ticket of its window
@@ -1853,9 +1872,23 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         if (!s_last) return;
         const double inv = ldexp(1.0, -grad_shift(wc[it.win], gmd, g.R));
         const int ncell = h * w * 2;
+        double stv = 0.0;                                    // gamma * 0.25 / (#non-zero TV pixels + eps) * 2^-tv_shift, as k_final forms it
+        if (tv_gamma != 0.0) {
+            double nz = 0.0;
+            for (int i = threadIdx.x; i < g.ntiles; i += NTH) nz += tvparts[((size_t)it.win * g.ntiles + i) * 3 + 1];
+            __shared__ double tvred[NTH / 64];
+            nz = block_sum<NTH / 64>(nz, tvred);
+            __shared__ double s_stv;
+            if (threadIdx.x == 0) s_stv = tv_gamma * 0.25 / (nz + EPSN) * ldexp(1.0, -tv_shift(g.H, g.W));
+            __syncthreads();
+            stv = s_stv;
+        }
+        unsigned long long* __restrict__ out_tv = reinterpret_cast<unsigned long long*>(gth_tv) + (size_t)it.win * gth_cap;
         for (int i = threadIdx.x; i < ncell; i += NTH) {
             const long long q = (long long)atomicExch(out + i, 0ull);
-            grad_out[(size_t)it.win * ncell + i] = (double)q * inv;
+            double v = (double)q * inv;
+            if (tv_gamma != 0.0) v += stv * (double)(long long)atomicExch(out_tv + i, 0ull);      // k_tv's own projection (an earlier kernel)
+            grad_out[(size_t)it.win * ncell + i] = v;
         }
         return;
     }
@@ -1973,12 +2006,20 @@ __global__ __launch_bounds__(NT) void k_tile_counts(Geom g, const int32_t* __res
 // grid (ntiles, B).  tvparts (B,ntiles,2) = {sum of abs, non-zero count}.
 // With unmasked != 0 also accumulates |div Theta| partial (regularizers.py:41-58) into tvparts[...,2].
 // ------------------------------------------------------------------------------------------------
+// PROJ_TV = 1 (theta grids whose tiles touch <= PG_MAXC x PG_MAXC cells): the tile's gradient values are projected onto the theta cells
+// here (gth_tv, i64 at tv_shift) instead of being written as an image for k_project: one launch and 16 B per pixel less per evaluation.
+template <int PROJ_TV>
 __global__ __launch_bounds__(NT) void k_tv(Geom g, const double* __restrict__ Theta, const uint8_t* __restrict__ mask,
-                                            double* __restrict__ tvg, double* __restrict__ tvparts, int want_thdiv)
+                                            double* __restrict__ tvg, double* __restrict__ tvparts, int want_thdiv,
+                                            int h, int w, const double* __restrict__ AH, const double* __restrict__ AW,
+                                            const TileRange* __restrict__ tilerng, long long* __restrict__ gth_tv, int gth_cap,
+                                            double* __restrict__ tvparts_host)      // or nullptr: a second copy of tvparts where the host reads it
 {
     constexpr int P2 = TS + 4, P1 = TS + 2;
-    __shared__ double f[2][P2][P2 + 1];
-    __shared__ float sg[4][P1][P1 + 1];       // sign(gx_0), sign(gy_0), sign(gx_1), sign(gy_1)
+    __shared__ __attribute__((aligned(16))) double f[2][P2][P2 + 1];
+    __shared__ __attribute__((aligned(16))) float sg[4][P1][P1 + 1];       // sign(gx_0), sign(gy_0), sign(gx_1), sign(gy_1)
+    static_assert(sizeof(double) * 2 * P2 * (P2 + 1) >= sizeof(double2) * TS * TS, "f holds the tile for the projection");
+    static_assert(sizeof(float) * 4 * P1 * (P1 + 1) >= PROJ_SCRATCH_BYTES, "sg holds the projection's scratch");
     __shared__ double scratch[NWAVE];
     const int tile = blockIdx.x, b = blockIdx.y;
     const int tx = tile % g.tilesX, ty = tile / g.tilesX;
@@ -2019,9 +2060,12 @@ __global__ __launch_bounds__(NT) void k_tv(Geom g, const double* __restrict__ Th
     }
     __syncthreads();
     double* __restrict__ out = tvg + (size_t)b * g.H * g.W * 2;
-    for (int p = threadIdx.x; p < TS * TS; p += NT) {
+    double2 mine[TS * TS / NT];                               // PROJ_TV: this thread's pixels, parked until every thread has read f's consumers (sg)
+    const double tvscale = ldexp(1.0, tv_shift(g.H, g.W));
+    for (int p = threadIdx.x, kq = 0; p < TS * TS; p += NT, ++kq) {
         const int ly = p / TS, lx = p % TS;
         const int y = y0 + ly, x = x0 + lx;
+        if (PROJ_TV) mine[kq] = make_double2(0.0, 0.0);
         if (y >= g.H || x >= g.W) continue;
         double o[2] = {0.0, 0.0};
         if (mk[(size_t)y * g.W + x]) {
@@ -2037,12 +2081,27 @@ __global__ __launch_bounds__(NT) void k_tv(Geom g, const double* __restrict__ Th
                 o[c] = -(ax + ay);
             }
         }
-        *reinterpret_cast<double2*>(out + ((size_t)y * g.W + x) * 2) = make_double2(o[0], o[1]);
+        if (PROJ_TV) mine[kq] = make_double2(o[0] * tvscale, o[1] * tvscale);
+        else *reinterpret_cast<double2*>(out + ((size_t)y * g.W + x) * 2) = make_double2(o[0], o[1]);
     }
     sabs = block_sum(sabs, scratch);
     cnt = block_sum(cnt, scratch);
     double* tp = tvparts + ((size_t)b * g.ntiles + tile) * 3;
-    if (threadIdx.x == 0) { tp[0] = sabs; tp[1] = cnt; tp[2] = 0.0; }
+    if (threadIdx.x == 0) {
+        tp[0] = sabs; tp[1] = cnt; tp[2] = 0.0;
+        if (tvparts_host) { double* th = tvparts_host + ((size_t)b * g.ntiles + tile) * 3; th[0] = sabs; th[1] = cnt; th[2] = 0.0; }
+    }
+    if (PROJ_TV) {
+        __syncthreads();                                     // f and sg are dead: the tile goes into f, the projection's scratch into sg
+        double2* vals = reinterpret_cast<double2*>(&f[0][0][0]);
+        for (int p = threadIdx.x, kq = 0; p < TS * TS; p += NT, ++kq) {
+            const int ly = p >> 5, lx = p & 31;
+            vals[(ly << 5) + (lx ^ ly)] = mine[kq];
+        }
+        project_tile_to_cells<NT>(g, h, w, tilerng[tile], x0, y0, AH, AW, vals, &sg[0][0][0],
+                                  reinterpret_cast<unsigned long long*>(gth_tv) + (size_t)b * gth_cap);
+        __syncthreads();                                     // (the report below reuses f)
+    }
 
     if (want_thdiv) {
         // per_pix_theta_divergence (regularizers.py:41-58): UNMASKED Theta
@@ -2098,12 +2157,6 @@ __global__ __launch_bounds__(NT) void k_tv(Geom g, const double* __restrict__ Th
 // than PROJ_CELLS: straight to HBM.
 // ------------------------------------------------------------------------------------------------
 constexpr int PROJ_CELLS = 1024;
-// |tvg| <= 2 * 32 per pixel and component (two adjoint Scharr stencils of +-1 images); times H*W pixels, times <= 4 for the weights
-__host__ __device__ __forceinline__ int tv_shift(int H, int W) {
-    int e = 0;
-    while ((double)(1ull << e) <= 256.0 * (double)H * (double)W) ++e;
-    return 61 - e;
-}
 __global__ __launch_bounds__(NT) void k_project(Geom g, int h, int w, int cap, int src0, int wide,
         const double* __restrict__ AH, const double* __restrict__ AW,
         const int2* __restrict__ rowtap, const int2* __restrict__ coltap,
