@@ -385,7 +385,7 @@ int ensure_resample(eincm_ctx* c, int h, int w, int method) {
     return EINCM_OK;
 }
 
-constexpr size_t ZERO_COPY_MAX = 16384;   // doubles of theta / gradient that cross PCIe by zero-copy access to pinned host memory
+constexpr size_t ZERO_COPY_MAX = 65536;   // doubles of theta / gradient that cross PCIe by zero-copy access to pinned host memory (a 64-window batch at 16x16: 32768)
 
 // The event kernels' workgroups take the segments by decreasing length (block_to_work): stable counting sort of the lengths.
 void order_by_length(const std::vector<int32_t>& lens, std::vector<int32_t>& order) {
