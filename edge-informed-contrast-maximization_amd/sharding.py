@@ -59,6 +59,26 @@ def shard_events(n_events, rank, world_size):
     return shard_windows(n_events, rank, world_size)
 
 
+def rs_ag_sum_(dist, t, world):
+    """In-place sum of ``t`` over the ranks as reduce_scatter + all_gather of equal chunks (padded with zeros to a multiple of the
+    world size).  Integer sums, so the result equals all_reduce's whatever the chunking; on point-to-point xGMI the two steps are
+    one-hop exchanges of 1/world of the buffer each."""
+    import torch
+    flat = t.reshape(-1)
+    n = flat.numel()
+    per = -(-n // world)
+    if per * world != n:                                    # a copy; the usual sizes divide
+        buf = torch.zeros(per * world, dtype=flat.dtype, device=flat.device)
+        buf[:n] = flat
+    else:
+        buf = flat
+    mine = torch.empty(per, dtype=flat.dtype, device=flat.device)
+    dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM)
+    dist.all_gather_into_tensor(buf, mine)
+    if buf is not flat:
+        flat.copy_(buf[:n])
+
+
 class ShardedEngine:
     """Event-sharded evaluation: every rank stages ITS slice of each window's events (edges replicated) in its own Engine.
     The IWE is additive over events (src/utils/event_utils.py:59 is a pure sum), so one exchange step suffices per
@@ -92,24 +112,16 @@ class ShardedEngine:
     def _allreduce_iwe_(self, t):
         """Sum of the (B,R,H,W) int64 accumulator over the ranks, in place."""
         import torch
-        D = self.dist
-        if self.on and self.gpu_collectives and self.iwe_collective == 'rs_ag':
-            flat = t.reshape(-1)
-            n = flat.numel()
-            per = -(-n // self.world)
-            if per * self.world != n:                       # pad to a multiple of the world size (a copy; the usual sizes divide)
-                buf = torch.zeros(per * self.world, dtype=flat.dtype, device=flat.device)
-                buf[:n] = flat
-            else:
-                buf = flat
-            mine = torch.empty(per, dtype=flat.dtype, device=flat.device)
-            D.reduce_scatter_tensor(mine, buf, op=D.ReduceOp.SUM)
-            D.all_gather_into_tensor(buf, mine)
-            if buf is not flat:
-                flat.copy_(buf[:n])
+        if not self.on or self.iwe_collective != 'rs_ag':
+            self._allreduce_(t, self.dist.ReduceOp.SUM)
+        elif self.gpu_collectives:
+            rs_ag_sum_(self.dist, t, self.world)            # NEVER RUN ON HARDWARE (no multi-GPU box so far); arithmetic covered on gloo
             torch.cuda.current_stream().synchronize()
-            return
-        self._allreduce_(t, D.ReduceOp.SUM)
+        else:                                               # gloo rehearsal: the same exchange on a host copy
+            h = t.cpu()
+            rs_ag_sum_(self.dist, h, self.world)
+            t.copy_(h)
+            torch.cuda.current_stream().synchronize()
 
     def _allreduce_(self, t, op):
         import torch

@@ -75,3 +75,42 @@ def test_two_rank_gloo_matches_single_process():
     for _, _, total, allv in res:
         assert total == pytest.approx(ref.sum(), rel=1e-12)     # identical on every rank
         np.testing.assert_allclose(allv, ref, rtol=1e-12)
+
+
+def _rs_ag_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sh = importlib.import_module('edge-informed-contrast-maximization_amd.sharding')
+    out = []
+    for shape in ((1, 5, 26, 34), (2, 3, 7, 9), (1, 1, 1, 1)):          # divisible by the world size, padded, smaller than it
+        rng = np.random.default_rng(17 * rank + sum(shape))
+        a = torch.from_numpy(rng.integers(-2**61 // world, 2**61 // world, size=shape, dtype=np.int64))
+        ref = a.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        sh.rs_ag_sum_(dist, a, world)
+        out.append(bool(torch.equal(a, ref)))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize('world', [2, 3])
+def test_reduce_scatter_all_gather_equals_all_reduce(world):
+    """sharding.rs_ag_sum_ (the `iwe_collective='rs_ag'` form of the accumulator exchange) gives all_reduce's integer sums for sizes that
+    divide by the world size, that need padding and that are smaller than it."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rs_ag_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(all(v) for v in res.values()), res

@@ -32,7 +32,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, iwe_collective='all_reduce'):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -46,7 +46,7 @@ def _worker(rank, world, port, q):
     mine = sh.shard_events(N, rank, world)
     sl = slice(mine.start, mine.stop)
     with engine.Engine((H, W), N, max_refs=R) as eng:
-        se = sh.ShardedEngine(eng)
+        se = sh.ShardedEngine(eng, iwe_collective=iwe_collective)
         se.set_windows([(win['xs'][sl], win['ys'][sl], win['ts'][sl], win['edges'], win['edge_ts'])])
         out = []
         for th, (hw, gamma, lvl) in zip(thetas, CASES):
@@ -106,13 +106,14 @@ def test_device_resident_finishing_half(built_lib):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_split_events_match_unsharded(built_lib):
+@pytest.mark.parametrize('iwe_collective', ['all_reduce', 'rs_ag'])
+def test_two_ranks_split_events_match_unsharded(built_lib, iwe_collective):
     from oracle import eincm_oracle as O
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, iwe_collective)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in range(world))
