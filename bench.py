@@ -199,6 +199,17 @@ def extra_legs(a, synth, engine, wins, base, dev_index, alpha, beta):
             e.set_window(wd['xs'], wd['ys'], wd['ts'], wd['edges'], wd['edge_ts'])
             ths = [np.ascontiguousarray(thd * (1.0 + 0.01 * k)) for k in range(3)]
             out['eval_ms_c3_dense'] = _timed_evals(e, ths, engine.make_params(alpha, beta, 0.0, 0.0, 0), n=15)
+            # the same evaluations with theta and gradient resident in HBM (eincm_loss_grad_device): what an optimiser on the GPU would see
+            import torch
+            pd = engine.make_params(alpha, beta, 0.0, 0.0, 0)
+            tds = [torch.from_numpy(t).to(f'cuda:{dev_index}') for t in ths]
+            vmax = float(np.abs(thd).max() * 1.03)
+
+            class _Dev:                      # _timed_evals calls .loss_grad(theta, p)
+                @staticmethod
+                def loss_grad(t, p):
+                    return e.loss_grad_device(t, p, theta_abs_max=vmax)
+            out['eval_ms_c3_dense_device_resident'] = _timed_evals(_Dev, tds, pd, n=15)
     except Exception as exc:          # noqa: BLE001
         out['eval_ms_c3_dense'] = {'error': repr(exc)[:200]}
     try:        # ---- C4 end to end: the 5-level solve of the 8 windows, lockstep batch solver against sequential solves

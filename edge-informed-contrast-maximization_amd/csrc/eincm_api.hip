@@ -127,6 +127,9 @@ struct eincm_ctx {
     double* d_AH = nullptr; double* d_AW = nullptr;     // (H,h) (W,w) capacity H*H, W*W? -> sized on demand
     int2* d_rowtap = nullptr; int2* d_coltap = nullptr;
     TileRange* d_tilerng = nullptr;    // (ntiles) coarse cells under each tile for the current theta shape
+    const double* theta_dev_in = nullptr;   // eincm_loss_grad_device: theta of the evaluation being begun lives in HBM (the caller's buffer)
+    double vmax_hint = -1.0;                // ... and this bounds |theta| for the window-capacity choice (< 0: unknown, largest windows)
+    double* grad_dev_out = nullptr;         // ... and the gradient goes there (device to device)
     bool device_results = false;       // eincm_set_device_results: results stay in HBM until eincm_finish_collect (event-sharded mode over RCCL)
     bool proj_in_gather = false;       // every tile touches <= PG_MAXC x PG_MAXC cells: k_gather projects its tile itself
     size_t AH_cap = 0, AW_cap = 0;
@@ -458,11 +461,14 @@ void launch_theta_image(eincm_ctx* c, int h, int w, bool identity, bool use_arg,
 int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_image, const double* theta_host, bool host_asm) {
     const Geom& g = c->g;
     const size_t nth = (size_t)h * w * 2;
-    const bool use_arg = !identity && (size_t)g.B * nth <= (size_t)THETA_ARG_MAX;
+    const bool use_arg = !c->theta_dev_in && !identity && (size_t)g.B * nth <= (size_t)THETA_ARG_MAX;
     const bool const_theta = !identity && h == 1 && w == 1;
     const double* theta_dev = c->d_theta_in;
     ThetaArg targ;
-    if (use_arg) {
+    if (c->theta_dev_in) {
+        theta_dev = c->theta_dev_in;                 // device-resident theta: the kernels read the caller's buffer, nothing crosses PCIe
+        if (const_theta) need_theta_image = true;    // (no host copy of theta for ensure_theta_image to rebuild the image from)
+    } else if (use_arg) {
         memcpy(targ.v, theta_host, (size_t)g.B * nth * sizeof(double));     // theta rides in the kernel arguments
     } else if ((size_t)g.B * nth <= ZERO_COPY_MAX) {
         // medium theta (e.g. 16x16): k_theta reads it straight from the pinned, GPU-mapped staging buffer (no copy command)
@@ -484,7 +490,7 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
         StageTimer t(c, EINCM_STAGE_THETA, const_theta ? !need_theta_image : c->itembase_valid);       // one kernel in either case
         const int nwin_threads = (c->n_items + c->n_items_s) * g.R;
         if (const_theta) {
-            c->last_theta11.assign(theta_host, theta_host + (size_t)g.B * 2);
+            if (theta_host) c->last_theta11.assign(theta_host, theta_host + (size_t)g.B * 2); else c->last_theta11.clear();
             c->Theta_valid = false;
             if (need_theta_image) launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev, false);
             // the event kernels derive their windows from theta themselves; the velocity bounds (tmm) only feed k_final's NaN scan,
@@ -624,7 +630,8 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         double vmax = 0.0;
         const size_t nall = (size_t)g.B * nth;
         const size_t stride = nall > 8192 ? nall / 8192 : 1;            // dense theta: sample (any capacity is correct; 65536 samples cost 90 us)
-        for (size_t i = 0; i < nall; i += stride) { const double a = std::fabs(theta_host[i]); if (a > vmax && std::isfinite(a)) vmax = a; }
+        if (c->theta_dev_in) vmax = (c->vmax_hint >= 0.0 && std::isfinite(c->vmax_hint)) ? c->vmax_hint : 1e9;      // unknown: the largest windows
+        else for (size_t i = 0; i < nall; i += stride) { const double a = std::fabs(theta_host[i]); if (a > vmax && std::isfinite(a)) vmax = a; }
         // time span of a typical splat segment: seg_s events out of the average tile population
         const double per_tile = (double)std::max<int64_t>(c->n_events, 1) / ((double)g.B * g.ntiles);
         const double tspan = std::min(1.0, (double)c->seg_s_used / std::max(per_tile, 1.0));
@@ -657,11 +664,11 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     // 2-DoF theta with nothing but the contrast and correlation terms (every level above 0 of the reference's pyramid at its first
     // level, and the bench workload): the scalar assembly and the sum of the gather's per-workgroup partials run on the host
     static const bool no_host_asm = getenv("EINCM_NO_HOST_ASM") != nullptr;
-    const bool grid_tail = !(h == 1 && w == 1) && c->proj_in_gather && c->itembase_valid && (size_t)g.B * nth <= ZERO_COPY_MAX;
+    const bool grid_tail = !(h == 1 && w == 1) && c->proj_in_gather && c->itembase_valid && (size_t)g.B * nth <= ZERO_COPY_MAX && !c->theta_dev_in;
     // (the TV term rides along on a theta grid: k_tv projects its own gradient and the gather's tail combines it; a 2-DoF theta with
     // TV - no level of the reference's pyramid - keeps k_final)
     const bool host_asm = want_grad && !identity && (((h == 1 && w == 1) && !ep.want_tv) || grid_tail) && !ep.want_div && !full_aux && !no_host_asm &&
-                          !c->device_results;
+                          !c->device_results && !c->theta_dev_in;
     if (host_asm) {
         c->theta_nan.assign((size_t)g.B, 0);
         for (int b = 0; b < g.B; ++b) {
@@ -684,6 +691,12 @@ int enqueue_result_copies(eincm_ctx* c) {
     const bool want_grad = c->pend.want_grad;
     const size_t nth = (size_t)c->pend.h * c->pend.w * 2;
     c->n_pieces = 0;
+    if (c->theta_dev_in) {                           // eincm_loss_grad_device: scalars to the host, the gradient device to device
+        HIPCHK(c, hipMemcpyAsync(c->h_outs, c->d_outs, (size_t)g.B * sizeof(OutScal), hipMemcpyDeviceToHost, c->stream));
+        if (want_grad && c->grad_dev_out)
+            HIPCHK(c, hipMemcpyAsync(c->grad_dev_out, c->d_grad, (size_t)g.B * nth * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return EINCM_OK;
+    }
     if (want_grad && (size_t)g.B * nth >= ((size_t)1 << 17)) {
         // a dense gradient (4.9 MB at 480x640): in pieces, an event behind each, so that eval_end_collect hands piece k over
         // (copy + finite scan on the host) while piece k + 1 is still crossing PCIe
@@ -731,7 +744,7 @@ int eval_end_launch(eincm_ctx* c) {
     static const bool compose_env = getenv("EINCM_COMPOSE") != nullptr;
     const bool compose = want_grad && !div_grad && compose_env;
     const bool g2_from_imgrad = !compose && want_grad && ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG;
-    const bool zero_copy_out = !c->device_results && !identity && (size_t)g.B * nth <= ZERO_COPY_MAX;
+    const bool zero_copy_out = !c->device_results && !c->theta_dev_in && !identity && (size_t)g.B * nth <= ZERO_COPY_MAX;
     const bool stream_stats = host_asm || (g2_from_imgrad && g.ntiles >= NSPART);
     const int n_imwg = (g.nig + IG_NT / 64 - 1) / (IG_NT / 64);
     unsigned* gmax_buf = compose ? c->d_gbound : c->d_gmax;
@@ -988,7 +1001,8 @@ int eval_end_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) 
     }
     c->pend.active = false; c->pend.launched = false;
     ++c->hp_n;
-    if (want_grad && !grad) return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
+    const bool dev_io = c->theta_dev_in != nullptr;           // the gradient went device to device (enqueue_result_copies)
+    if (want_grad && !grad && !dev_io) return fail(c, EINCM_ERR_ARG, "the evaluation was begun with a gradient but grad is NULL");
     HostPhase hp(c, EINCM_HP_COLLECT);
     if (c->pend.host_asm) host_assemble(c);
     int rc = collect_timings(c);
@@ -1001,7 +1015,7 @@ int eval_end_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) 
         if (b < 64 && !((g.wmask >> b) & 1ull)) {               // not evaluated: NaN value, zero gradient, no verdict
             if (value) value[b] = NAN;
             if (aux) { aux[b].final_loss = NAN; aux[b].mean_rel_corr = NAN; aux[b].mean_rel_contrast = NAN; aux[b].mean_rel_iwe_divergence = NAN; aux[b].theta_total_variation = NAN; }
-            if (want_grad && c->n_pieces == 0) for (size_t i = 0; i < nth; ++i) c->h_grad[(size_t)b * nth + i] = 0.0;
+            if (want_grad && c->n_pieces == 0 && !dev_io) for (size_t i = 0; i < nth; ++i) c->h_grad[(size_t)b * nth + i] = 0.0;
             continue;
         }
         const OutScal& o = c->h_outs[b];
@@ -1016,7 +1030,7 @@ int eval_end_collect(eincm_ctx* c, double* value, double* grad, eincm_aux* aux) 
         if (o.nonfinite != 0.0) nonfinite = true;
     }
     if (piece_bad) nonfinite = true;
-    if (want_grad && c->n_pieces == 0) {
+    if (want_grad && c->n_pieces == 0 && !dev_io) {
         // copy out and look for NaN/Inf in the same pass; an integer OR-reduction over the exponent bits vectorises, an
         // early-exit std::isfinite loop does not (0.6 ms of a 1.8 ms dense-theta evaluation at 480x640)
         const size_t n = (size_t)g.B * nth;
@@ -1161,11 +1175,11 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_wins, (size_t)c->max_items * max_refs));
     TRY(dalloc(&c->d_wins_s, (size_t)c->max_items * max_refs));
     c->host_binning = (ntiles > BIN_MAX_TILES) || (getenv("EINCM_HOST_BINNING") != nullptr);
+    TRY(dalloc(&c->d_raw_x, (size_t)max_events_total));          // kept after staging: eincm_get_warped_events walks them
+    TRY(dalloc(&c->d_raw_y, (size_t)max_events_total));
+    TRY(dalloc(&c->d_raw_t, (size_t)max_events_total));
     if (!c->host_binning) {
         c->max_binblocks = max_events_total / BIN_CHUNK + (int64_t)B + 1;
-        TRY(dalloc(&c->d_raw_x, (size_t)max_events_total));
-        TRY(dalloc(&c->d_raw_y, (size_t)max_events_total));
-        TRY(dalloc(&c->d_raw_t, (size_t)max_events_total));
         TRY(dalloc(&c->d_binblocks, (size_t)c->max_binblocks));
         TRY(dalloc(&c->d_win_blk, B + 1));
         TRY(dalloc(&c->d_blockhist, (size_t)c->max_binblocks * ntiles));
@@ -1521,6 +1535,16 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     if (N > 0) {
         HIPCHK(c, hipMemcpyAsync(c->d_xy, sxy.data(), (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_t, st.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        int64_t off = 0;                                   // the events as handed over (eincm_get_warped_events), like the device path keeps them
+        for (int b = 0; b < n_windows; ++b) {
+            const size_t nb = (size_t)n_events[b];
+            if (nb > 0) {
+                HIPCHK(c, hipMemcpyAsync(c->d_raw_x + off, xs_w[b], nb * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->d_raw_y + off, ys_w[b], nb * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->d_raw_t + off, ts_w[b], nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            }
+            off += (int64_t)nb;
+        }
     }
     if (!items.empty()) {
         HIPCHK(c, hipMemcpyAsync(c->d_items, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
@@ -1677,6 +1701,34 @@ int eincm_finish_loss_grad(eincm_ctx* c, double* value, double* grad, eincm_aux*
     if (c->constants_pending) return fail(c, EINCM_ERR_STATE, "window constants pending (eincm_finish_constants)");
     HIPCHK(c, hipSetDevice(c->device));
     return eval_end(c, value, grad, aux);
+}
+
+// theta and gradient resident in HBM (a caller whose optimiser lives on the GPU): nothing but the scalars crosses PCIe.
+int eincm_loss_grad_device(eincm_ctx* c, const double* theta_dev, int h, int w, const eincm_params* p, double theta_abs_max,
+                           double* value, double* grad_dev, eincm_aux* aux) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!c->staged) return fail(c, EINCM_ERR_STATE, "eincm_loss_grad_device called before eincm_set_windows");
+    if (!theta_dev || !p || !value || h < 1 || w < 1) return fail(c, EINCM_ERR_ARG, "bad argument");
+    if (p->method < 0 || p->method > EINCM_METHOD_CUBIC) return fail(c, EINCM_ERR_ARG, "method %d unknown", p->method);
+    if (c->constants_pending) return fail(c, EINCM_ERR_STATE, "window constants pending (eincm_finish_constants)");
+    if (c->device_results) return fail(c, EINCM_ERR_STATE, "eincm_set_device_results is on: use the split finishing half");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, theta_dev) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != c->device) {
+        (void)hipGetLastError();
+        return fail(c, EINCM_ERR_ARG, "theta_dev is not memory of device %d", c->device);
+    }
+    if (grad_dev && (hipPointerGetAttributes(&at, grad_dev) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != c->device)) {
+        (void)hipGetLastError();
+        return fail(c, EINCM_ERR_ARG, "grad_dev is not memory of device %d", c->device);
+    }
+    struct Reset { eincm_ctx* c; ~Reset() { c->theta_dev_in = nullptr; c->grad_dev_out = nullptr; c->vmax_hint = -1.0; } } reset{c};
+    c->theta_dev_in = theta_dev; c->grad_dev_out = grad_dev; c->vmax_hint = theta_abs_max;
+    int rc = eval_begin(c, nullptr, h, w, p, grad_dev != nullptr);
+    if (rc) return rc;
+    rc = eval_end_launch(c);
+    if (rc) { (void)hipStreamSynchronize(c->stream); c->pend.active = false; c->pend.launched = false; return rc; }
+    return eval_end_collect(c, value, nullptr, aux);
 }
 
 int eincm_set_device_results(eincm_ctx* c, int on) {
@@ -1938,6 +1990,34 @@ static int ensure_buf(eincm_ctx* c, DevBuf& b, size_t bytes) {
     return EINCM_OK;
 }
 #define ENSURE(c, buf, bytes) do { const int rc_ = ensure_buf((c), (buf), (bytes)); if (rc_ != EINCM_OK) return rc_; } while (0)
+
+// 'warped_xs' / 'warped_ys' of compute_loss_objectives (losses.py:58,90-91) for one window under the last evaluation's theta
+int eincm_get_warped_events(eincm_ctx* c, int window, double* warped_xs, double* warped_ys) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!warped_xs || !warped_ys) return fail(c, EINCM_ERR_ARG, "null pointer argument");
+    if (!c->staged || !c->have_eval) return fail(c, EINCM_ERR_STATE, "no evaluation yet");
+    const Geom& g = c->g;
+    if (window < 0 || window >= g.B) return fail(c, EINCM_ERR_ARG, "window %d of %d", window, g.B);
+    HIPCHK(c, hipSetDevice(c->device));
+    { const int rc = ensure_theta_image(c); if (rc) return rc; }
+    const int64_t n = c->win_events[window];
+    if (n == 0) return EINCM_OK;
+    int64_t off = 0;
+    for (int b = 0; b < window; ++b) off += c->win_events[b];
+    const size_t bytes = (size_t)g.R * (size_t)n * sizeof(double);
+    ENSURE(c, c->e_a, 2 * bytes);                              // scratch of the edge routines: free between calls
+    double* dx = static_cast<double*>(c->e_a.p);
+    double* dy = dx + (size_t)g.R * (size_t)n;
+    const int grid = (int)std::min<int64_t>((n + NT - 1) / NT, 8192);
+    hipLaunchKernelGGL(k_warp_events, dim3(grid), dim3(NT), 0, c->stream, g, window, (long long)n, c->d_raw_x + off, c->d_raw_y + off,
+                       c->d_raw_t + off, c->d_Theta, c->d_edge_ts, dx, dy);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(warped_xs, dx, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(warped_ys, dy, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return EINCM_OK;
+}
+
 
 int eincm_inv_dist_transform(eincm_ctx* c, const uint8_t* edge_img, int n, int formulation, double alpha, double d_sat,
                              double* out, int32_t* sqdist) {

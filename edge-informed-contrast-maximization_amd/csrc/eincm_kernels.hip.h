@@ -1951,6 +1951,29 @@ __global__ __launch_bounds__(NT) void k_count(Geom g, int n_items, const Item* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_warp_events: the warped coordinates themselves, warped[r, i] = x_i - Theta[y_i, x_i] * (t_i - tau_r), for ONE window's events in the
+// order the caller handed them over (the raw upload of staging): the 'warped_xs' / 'warped_ys' entries of compute_loss_objectives
+// (losses.py:58,90-91; event_warpers.py:34-35), which only plotters read.  Same two roundings as warp_axis.  Not on the evaluation path.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_warp_events(Geom g, int win, long long n, const int16_t* __restrict__ xs, const int16_t* __restrict__ ys,
+                                                     const double* __restrict__ ts, const double* __restrict__ Theta,
+                                                     const double* __restrict__ edge_ts, double* __restrict__ wx, double* __restrict__ wy)
+{
+#pragma clang fp contract(off)
+    const double* __restrict__ Th = Theta + (size_t)win * g.H * g.W * 2;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        const int x = xs[i], y = ys[i];
+        const double t = ts[i];
+        const double2 v = *reinterpret_cast<const double2*>(Th + ((size_t)y * g.W + x) * 2);
+        for (int r = 0; r < g.R; ++r) {
+            const double dt = t - edge_ts[win * g.R + r];
+            wx[(size_t)r * n + i] = (double)x - v.x * dt;
+            wy[(size_t)r * n + i] = (double)y - v.y * dt;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_mask: event-presence mask (event_utils.py:64-76 / theta_utils.py:59-71).  grid-stride over events.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_mask(Geom g, const Item* __restrict__ items, int n_items, const uint32_t* __restrict__ ev_xy,

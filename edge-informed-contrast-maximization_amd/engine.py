@@ -243,6 +243,32 @@ class Engine:
         auxl = [{k: getattr(a, k) for k, _ in L.Aux._fields_} for a in aux] if want_aux else None
         return value, grad, auxl
 
+    # -- theta and gradient resident in HBM (an optimiser that lives on the GPU) -------------------------------------------
+    def loss_grad_device(self, theta, params, theta_abs_max=None, want_grad=True, want_aux=False, allow_nonfinite=True):
+        """theta: torch float64 CUDA tensor (B,h,w,2) (or (h,w,2) when B == 1) on the engine's device.  Returns (value ndarray (B,),
+        grad torch tensor like theta | None, aux list | None); nothing but the scalars crosses PCIe.  theta_abs_max: an upper bound of
+        |theta| if the caller has one on the host (it only selects LDS window capacities; None = unknown)."""
+        import torch
+        if not (isinstance(theta, torch.Tensor) and theta.is_cuda and theta.dtype == torch.float64):
+            raise TypeError('theta must be a float64 CUDA tensor')
+        th = theta.contiguous()
+        if th.dim() == 3:
+            th = th[None]
+        if th.dim() != 4 or th.shape[0] != self.B or th.shape[3] != 2:
+            raise ValueError(f'theta must be ({self.B},h,w,2), got {tuple(theta.shape)}')
+        grad = torch.empty_like(th) if want_grad else None
+        torch.cuda.current_stream(th.device).synchronize()              # the engine's kernels run on its own stream
+        value = np.empty(self.B, dtype=np.float64)
+        aux = (L.Aux * self.B)() if want_aux else None
+        rc = self._lib.eincm_loss_grad_device(self._ctx, C.c_void_p(th.data_ptr()), int(th.shape[1]), int(th.shape[2]), C.byref(params),
+                                              -1.0 if theta_abs_max is None else float(theta_abs_max), _dp(value),
+                                              C.c_void_p(grad.data_ptr()) if want_grad else None, aux)
+        self._check(rc, allow_nonfinite)
+        if want_grad and theta.dim() == 3:
+            grad = grad[0]
+        auxl = [{k: getattr(a, k) for k, _ in L.Aux._fields_} for a in aux] if want_aux else None
+        return value, grad, auxl
+
     def finish_constants(self):
         self._check(self._lib.eincm_finish_constants(self._ctx))
 
@@ -367,6 +393,15 @@ class Engine:
         a = np.empty((self.B, self.R, self.H, self.W), dtype=np.uint32)
         self._check(self._lib.eincm_get_count_images(self._ctx, a.ctypes.data_as(C.POINTER(C.c_uint32))))
         return a
+
+    def warped_events(self, window=0):
+        """(warped_xs, warped_ys), (R, n_events) float64 each: per_pix_warp of one window's events (caller's order) at every reference
+        time under the last evaluation's Theta - the two per-event entries of compute_loss_objectives (losses.py:58,90-91)."""
+        n = int(self.n_events[window]) if 0 <= window < self.B else 0        # (the library reports a bad index)
+        wx = np.empty((self.R, n), dtype=np.float64)
+        wy = np.empty((self.R, n), dtype=np.float64)
+        self._check(self._lib.eincm_get_warped_events(self._ctx, int(window), _dp(wx), _dp(wy)))
+        return wx, wy
 
     def scaled_theta(self):
         a = np.empty((self.B, self.H, self.W, 2), dtype=np.float64)

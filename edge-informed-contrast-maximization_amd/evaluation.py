@@ -52,9 +52,9 @@ def sparse_flow_error(pred_flow, gt_flow, event_mask=None):
 
 def evaluate_theta_array(theta_array, eval_xs, eval_ys, eval_ts, edges, edge_ts, gt_flow, alpha, beta, gamma, delta,
                          sensor_size, err_eval_event_mask=None):
-    """theta_eval.py:14-95 -> (evals dict, loss_obj dict).  The per-event warped coordinates and the IWE stay on the GPU;
+    """theta_eval.py:14-95 -> (evals dict, loss_obj dict).  The per-event warped coordinates (not used by the evaluation) and the IWE stay on the GPU;
     ``iwe_var`` is var(IWE at the first reference time) = flow_warp_losses[0] * var(IUE)."""
-    lo = losses.compute_loss_objectives(theta_array, eval_xs, eval_ys, eval_ts, edges, edge_ts, sensor_size)
+    lo = losses.compute_loss_objectives(theta_array, eval_xs, eval_ys, eval_ts, edges, edge_ts, sensor_size, warped_events=False)
     mean_rel_contrast = float(lo['rel_contrasts'].mean())
     mean_rel_corr = float(lo['rel_correlations'].mean())
     mean_rel_iwe_div = float(lo['rel_iwe_divergences'].mean())

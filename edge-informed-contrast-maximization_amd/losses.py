@@ -4,7 +4,7 @@ Same names, argument order and meaning as /root/reference/src/eincm/losses.py:
     loss_func(theta, xs, ys, ts, edges, edge_ts, alpha, beta, gamma, delta, cur_pyr_lvl, n_pyr_lvls,
               sensor_size, scale_to_sensor_size_method) -> (final_loss, aux_info)          losses.py:108-205
     handover_loss_func(alpha_handover, prev_theta, theta, xs, ..., method) -> loss          losses.py:208-276
-    compute_loss_objectives(theta, xs, ys, ts, edges, edge_ts, sensor_size) -> dict         losses.py:49-105
+    compute_loss_objectives(theta, xs, ys, ts, edges, edge_ts, sensor_size) -> dict         losses.py:49-105 (all 15 keys)
 so the hydra plugin point (configs/theta_loss_func/default.yaml:1-2, ``_target_: eincm.losses.loss_func``)
 can name this module instead.  The reference differentiates ``loss_func`` with JAX inside jaxopt; a HIP
 engine cannot be traced, so the gradient is exposed explicitly as ``value_and_grad_loss_func`` /
@@ -124,8 +124,11 @@ def handover_loss_func(alpha_handover, prev_theta, theta, xs, ys, ts, edges, edg
     return float(v[0])
 
 
-def compute_loss_objectives(theta, xs, ys, ts, edges, edge_ts, sensor_size):
-    """losses.py:49-105 on a full-resolution theta (H,W,2).  Per-event ``warped_xs/ys`` are not returned (they
-    never leave the GPU); every scalar key of the reference dict is."""
+def compute_loss_objectives(theta, xs, ys, ts, edges, edge_ts, sensor_size, warped_events=True):
+    """losses.py:49-105 on a full-resolution theta (H,W,2): every key of the reference dict.  The per-event ``warped_xs`` /
+    ``warped_ys`` ((R, n_events) float64, read by plotters only) cost a 2*R*n_events*8-byte copy: ``warped_events=False`` skips them."""
     eng = engine_for(xs, ys, ts, edges, edge_ts, sensor_size)
-    return eng.objectives(np.asarray(theta, dtype=np.float64))[0]
+    d = eng.objectives(np.asarray(theta, dtype=np.float64))[0]
+    if warped_events:
+        d['warped_xs'], d['warped_ys'] = eng.warped_events(0)
+    return d

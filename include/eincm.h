@@ -23,8 +23,9 @@
 extern "C" {
 #endif
 
-#define EINCM_ABI_VERSION 4   /* 2: eincm_iwe_device_ptr hands out the u64 fixed-point accumulator of the IWE stack; 3: eincm_set_timed_kernels, eincm_set_windows_ptrs;
-                                * 4: eincm_loss_grad_masked, eincm_set_device_results / eincm_finish_launch / eincm_grad_device_ptr / eincm_finish_collect, eincm_get_host_profile */
+#define EINCM_ABI_VERSION 5   /* 2: eincm_iwe_device_ptr hands out the u64 fixed-point accumulator of the IWE stack; 3: eincm_set_timed_kernels, eincm_set_windows_ptrs;
+                                * 4: eincm_loss_grad_masked, eincm_set_device_results / eincm_finish_launch / eincm_grad_device_ptr / eincm_finish_collect, eincm_get_host_profile;
+                               * 5: eincm_get_warped_events, eincm_loss_grad_device */
 
 #define EINCM_OK               0
 #define EINCM_ERR_ARG         -1   /* bad argument (shape, null pointer, out-of-range event coordinate) */
@@ -199,6 +200,12 @@ int eincm_get_scaled_theta(eincm_ctx* ctx, double* scaled_theta);
  * Overwrites the dL/dIWE image of the last evaluation (eincm_get_image_grad must be called before it). */
 int eincm_get_count_images(eincm_ctx* ctx, uint32_t* counts);
 
+/* The warped coordinates themselves: warped_xs[r,i] = x_i - Theta[y_i,x_i,0]*(t_i - tau_r) (and ys with component 1) of ONE window's events,
+ * in the order they were handed to eincm_set_windows, under the Theta of the last evaluation: the 'warped_xs' / 'warped_ys' entries of
+ * compute_loss_objectives (src/eincm/losses.py:58,90-91; per_pix_warp, src/eincm/event_warpers.py:28-37), read only by plotters.
+ * warped_xs, warped_ys: (n_refs, n_events[window]) float64 each.  Same operations as the evaluation's warp (product rounded first). */
+int eincm_get_warped_events(eincm_ctx* ctx, int window, double* warped_xs, double* warped_ys);
+
 /* compute_weights_for_multi_reference (losses.py:39-46) */
 int eincm_multi_ref_weights(int n_refs, double* w);
 
@@ -223,6 +230,19 @@ int eincm_get_host_profile(eincm_ctx* ctx, double* us /* EINCM_N_HOST_PHASES */,
 /* sums of the per-evaluation timings since the last reset, and how many evaluations they cover (a bench reads them once after
  * its timed loop instead of calling eincm_get_timings inside it) */
 int eincm_get_timings_total(eincm_ctx* ctx, eincm_timings* sum, int64_t* n_evals, int reset);
+
+/* The evaluation with theta AND gradient resident in HBM, for a caller whose optimiser lives on the GPU: only the scalars cross PCIe
+ * (a dense theta at 480x640 otherwise moves 2 x 4.9 MB per evaluation: ~380 of its ~590 us).  The reference's optimiser is on the host
+ * (src/eincm/solver.py:165-173), so this has no counterpart there.
+ *   theta_dev      (n_windows, h, w, 2) float64 in the memory of the context's device, complete when the call is made (the engine runs
+ *                  on its own stream: synchronise the stream that produced theta first)
+ *   theta_abs_max  an upper bound of |theta| (px per unit time) if the caller has one, < 0 otherwise: it only selects the capacity of
+ *                  the LDS windows (any value is correct; a bound far too small or unknown costs speed)
+ *   value          (n_windows) on the HOST; aux optional, on the host
+ *   grad_dev       (n_windows, h, w, 2) float64 on the device, or NULL for a forward-only evaluation; complete on return
+ * EINCM_ERR_NONFINITE reports a non-finite value or theta (the device gradient is not scanned). */
+int eincm_loss_grad_device(eincm_ctx* ctx, const double* theta_dev, int h, int w, const eincm_params* p, double theta_abs_max,
+                           double* value, double* grad_dev, eincm_aux* aux);
 
 /* Event-sharded mode over a GPU collective (RCCL): keep the results of the finishing half in HBM so that the caller can all-reduce
  * the gradient there, instead of bouncing it through the host.  eincm_set_device_results(ctx, 1) once; then per evaluation

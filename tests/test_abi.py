@@ -30,7 +30,7 @@ def test_header_symbols_exported(built_lib):
 def test_binding_table_matches_header(built_lib):
     L = importlib.import_module('edge-informed-contrast-maximization_amd._lib')
     assert sorted(n for n, _, _ in L.SIGNATURES) == _declared_symbols()
-    assert built_lib.eincm_abi_version() == 4
+    assert built_lib.eincm_abi_version() == 5
 
 
 def test_struct_layouts(built_lib, tmp_path):

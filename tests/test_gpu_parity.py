@@ -468,12 +468,40 @@ def test_reference_shaped_callables():
     assert v2 == pytest.approx(v_ref, rel=TOL) and rel(g, g_ref) <= TOL
     lo_ref = O.compute_loss_objectives(aux_ref['scaled_theta'], *a, (H, W))
     lo = losses.compute_loss_objectives(aux_ref['scaled_theta'], *a, (H, W))
+    assert set(k for k in lo_ref if not k.startswith('_')) <= set(lo)       # every key of losses.py:89-105
     for k, vref in lo_ref.items():
-        if k.startswith('_') or k in ('warped_xs', 'warped_ys'):
+        if k.startswith('_'):
+            continue
+        if k in ('warped_xs', 'warped_ys'):                                 # fp64, the reference's two roundings: bit for bit
+            assert lo[k].shape == vref.shape and np.array_equal(lo[k], vref), k
             continue
         assert rel(lo[k], vref) <= TOL, k
     assert len(losses._CACHE) == 1             # one staged window reused by all four calls
     losses.clear_engine_cache()
+
+
+def test_warped_events_of_a_batch(monkeypatch):
+    """eincm_get_warped_events: per window of a batch, caller's event order, 2-DoF theta (no Theta image until asked), a theta grid, and the
+    host-binned staging path; bit for bit the oracle's per_pix_warp (event_warpers.py:28-37)."""
+    H, W, R = 64, 96, 3
+    wins = [synth.make_window(80 + b, (H, W), n, R, flow='smooth', flow_mag=6.0) for b, n in enumerate((5000, 0, 1777))]
+    for host_binning in (False, True):
+        if host_binning:
+            monkeypatch.setenv('EINCM_HOST_BINNING', '1')
+        with engine.Engine((H, W), 7000, max_refs=R, max_windows=3) as eng:
+            eng.set_windows([win_args(w) for w in wins])
+            for hw in ((1, 1), (4, 4)):
+                th = np.stack([synth.theta_near_truth(80 + b, w, hw) for b, w in enumerate(wins)])
+                eng.loss_grad(th, engine.make_params(20.0, 35.0, 0.0, 0.0, 2))
+                Theta = eng.scaled_theta()
+                for b, w in enumerate(wins):
+                    wx, wy = eng.warped_events(b)
+                    assert wx.shape == wy.shape == (R, len(w['xs']))
+                    for r in range(R):
+                        rx, ry = O.per_pix_warp(Theta[b], w['xs'], w['ys'], w['ts'], w['edge_ts'][r], 1.0)
+                        assert np.array_equal(wx[r], rx) and np.array_equal(wy[r], ry), (host_binning, hw, b, r)
+            with pytest.raises(engine.EincmError):
+                eng.warped_events(3)
 
 
 # ---------------------------------------------------------------------------------------------------
