@@ -19,6 +19,12 @@ import numpy as np
 import scipy.optimize as spo
 from scipy.optimize._dcsrch import DCSRCH            # MINPACK-2 dcsrch as SciPy ships it: reverse communication, one step per call
 from scipy.optimize._linesearch import line_search_wolfe2
+from scipy.linalg.blas import dsymv, dsyr2
+
+try:                                                 # level-2 BLAS on a 512 x 512 matrix must not fan out over the host's cores
+    from threadpoolctl import threadpool_limits      # (OpenBLAS with 8+ threads: 15 ms per dsyr2 instead of 0.1 ms)
+except ImportError:                                  # without it the update stays in plain numpy
+    threadpool_limits = None
 
 from .engine import Engine, make_params
 from .solver import ScipyMinimizeInfo, EmptyCallback, rescale_theta, _canon
@@ -109,7 +115,9 @@ class _WindowBFGS:
         g = np.array(g, dtype=np.float64).reshape(-1)
         if self.phase == 'init':
             self.xk, self.old_fval, self.gfk = self.x0, f, g
-            self.Hk = np.eye(self.n)
+            self.sym = threadpool_limits is not None and self.n > _EXACT_UPDATE_MAX_N
+            # sym: the inverse Hessian lives in the UPPER triangle of a Fortran-ordered array (dsymv / dsyr2 touch half the matrix)
+            self.Hk = np.asfortranarray(np.eye(self.n)) if self.sym else np.eye(self.n)
             self.old_old_fval = self.old_fval + np.linalg.norm(self.gfk) / 2          # initial step guess dx ~ 1
             self.gnorm = np.abs(self.gfk).max() if self.n else 0.0
             self._begin_iteration(single_eval)
@@ -127,7 +135,7 @@ class _WindowBFGS:
     def _begin_iteration(self, single_eval):
         if not (self.gnorm > self.gtol and self.k < self.maxiter):
             return self._finish()
-        self.pk = -np.dot(self.Hk, self.gfk)
+        self.pk = -dsymv(1.0, self.Hk, self.gfk, lower=0) if self.sym else -np.dot(self.Hk, self.gfk)
         derphi0 = float(np.dot(self.gfk, self.pk))
         # scalar_search_wolfe1: the first trial step
         if self.old_old_fval is not None and derphi0 != 0:
@@ -207,12 +215,17 @@ class _WindowBFGS:
             A2 = I - yk[:, np.newaxis] * sk[np.newaxis, :] * rhok
             self.Hk = np.dot(A1, np.dot(self.Hk, A2)) + (rhok * sk[:, np.newaxis] * sk[np.newaxis, :])
         else:
-            # the same update as two rank-one corrections, O(n^2) instead of the two n x n products (n = 512 at a 16x16 theta:
-            # 10 ms per iteration in SciPy's form, the evaluation itself takes 0.1 ms):
+            # the same update as ONE symmetric rank-two correction, O(n^2) instead of the two n x n products (n = 512 at a 16x16
+            # theta: 10 ms per iteration in SciPy's form, the evaluation itself takes 0.1 ms):
             #   (I - r s y^T) H (I - r y s^T) + r s s^T = H - r (s (Hy)^T + (Hy) s^T) + r (1 + r y^T H y) s s^T     (H symmetric)
-            Hy = np.dot(self.Hk, yk)
-            self.Hk = (self.Hk - rhok * (np.outer(sk, Hy) + np.outer(Hy, sk))
-                       + (rhok * (1.0 + rhok * float(np.dot(yk, Hy)))) * np.outer(sk, sk))
+            #                                         = H + s w^T + w s^T,   w = (c / 2) s - r Hy,  c = r (1 + r y^T H y)
+            Hy = dsymv(1.0, self.Hk, yk, lower=0) if self.sym else np.dot(self.Hk, yk)
+            w = (0.5 * rhok * (1.0 + rhok * float(np.dot(yk, Hy)))) * sk - rhok * Hy
+            if self.sym:
+                self.Hk = dsyr2(1.0, sk, w, a=self.Hk, overwrite_a=1, lower=0)     # in place, upper triangle
+            else:
+                sw = np.outer(sk, w)
+                self.Hk = self.Hk + sw + sw.T
         self._begin_iteration(single_eval)
 
     def _finish(self):
@@ -224,6 +237,11 @@ class _WindowBFGS:
         elif np.isnan(self.gnorm) or np.isnan(fval) or np.isnan(self.xk).any():
             self.warnflag = 3
         self.phase, self.request = 'done', None
+        if getattr(self, 'sym', False):                             # hand out the full matrix
+            d = self.Hk.diagonal().copy()                          # (the strictly lower triangle is still the identity's: zero)
+            self.Hk = self.Hk + self.Hk.T
+            self.Hk[np.diag_indices(self.n)] = d
+            self.sym = False
         self.result = spo.OptimizeResult(fun=fval, jac=self.gfk, hess_inv=self.Hk, nfev=self.nfev, njev=self.nfev,
                                          status=self.warnflag, success=(self.warnflag == 0), x=self.xk, nit=self.k)
 
@@ -261,6 +279,12 @@ class LockstepBFGS:
 
     def run(self):
         """List of scipy OptimizeResult (None for inactive windows)."""
+        if threadpool_limits is not None:
+            with threadpool_limits(limits=1, user_api='blas'):
+                return self._run()
+        return self._run()
+
+    def _run(self):
         while True:
             req = [(b, w) for b, w in enumerate(self.windows) if w is not None and w.request is not None]
             if not req:

@@ -103,3 +103,24 @@ def test_inactive_windows_ride_along():
     res = drv.run()
     assert res[1] is None and res[0].success and res[2].success
     assert all(np.array_equal(c[1], x0[1]) for c in calls)          # the rider's point never moves
+
+
+def test_triangular_blas_update_equals_the_numpy_form(monkeypatch):
+    """Above 64 unknowns the inverse Hessian is kept in one triangle and updated by dsyr2 / read by dsymv (with BLAS threading off);
+    without threadpoolctl the same rank-two correction runs in plain numpy.  Same iterates to rounding, same symmetric hess_inv."""
+    n = 96
+    rng = np.random.default_rng(1)
+    A = rng.normal(size=(n, n)); A = A @ A.T + n * np.eye(n)
+    b = rng.normal(size=n)
+
+    def fun_batch(X, mask):
+        return np.array([0.5 * x @ A @ x - b @ x for x in X]), np.stack([A @ x - b for x in X])
+    x0 = rng.normal(size=(2, n))
+    r_blas = bs.LockstepBFGS(fun_batch, x0, 200, 1e-9).run()
+    monkeypatch.setattr(bs, 'threadpool_limits', None)
+    r_np = bs.LockstepBFGS(fun_batch, x0, 200, 1e-9).run()
+    for a, c in zip(r_blas, r_np):
+        assert a.success and c.success and a.nit == c.nit
+        assert np.abs(a.x - c.x).max() <= 1e-12 and np.abs(a.x - np.linalg.solve(A, b)).max() <= 1e-9
+        assert np.array_equal(a.hess_inv, a.hess_inv.T)
+        assert np.abs(a.hess_inv - c.hess_inv).max() <= 1e-9 * np.abs(c.hess_inv).max()
