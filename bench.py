@@ -248,32 +248,44 @@ def c4_solve_leg(a, wins, sensor, alpha, beta, dev_index, n_lvls=5, maxiter=40):
     def counting(*aa, **kk):
         n_calls[0] += 1
         return losses.value_and_grad_loss_func(*aa, **kk)
-    t_s, fin_s, fin_b = 0.0, [], []
+    t_s, t_s2, fin_s, fin_s2, fin_b, n_calls2 = 0.0, 0.0, [], [], [], 0
     for b in range(n_seq):
-        s = sol.MultipleLevelEINCMSolver(n_pyr_lvls=n_lvls, theta_opt_maxiters=maxit,
-                                         theta_loss_pfunc=partial(counting, n_pyr_lvls=n_lvls, sensor_size=sensor, **loss),
-                                         theta_opt_solver_params=sp, pyramid_bases=[2] * (n_lvls - 1))
-        s.set_datasample(*args[b])
         losses.engine_for(*args[b], sensor)              # staging outside the timer, like the batched side
-        t0 = time.perf_counter()
-        o = s.solve()
-        t_s += time.perf_counter() - t0
-        fin_s.append(float(o['theta_opt_state_pyr']['pyr_lvl_0'].fun_val))
+        for upd in ('scipy', 'rank2'):                   # SciPy's BFGS as the reference runs it; the same driver with the O(n^2) update
+            c0 = n_calls[0]
+            s = sol.MultipleLevelEINCMSolver(n_pyr_lvls=n_lvls, theta_opt_maxiters=maxit,
+                                             theta_loss_pfunc=partial(counting, n_pyr_lvls=n_lvls, sensor_size=sensor, **loss),
+                                             theta_opt_solver_params={**sp, 'bfgs_update': upd}, pyramid_bases=[2] * (n_lvls - 1))
+            s.set_datasample(*args[b])
+            t0 = time.perf_counter()
+            o = s.solve()
+            dt = time.perf_counter() - t0
+            fv = float(o['theta_opt_state_pyr']['pyr_lvl_0'].fun_val)
+            if upd == 'scipy':
+                t_s += dt; fin_s.append(fv)
+            else:
+                t_s2 += dt; fin_s2.append(fv); n_calls2 += n_calls[0] - c0
         fin_b.append(float(out_b[b]['theta_opt_state_pyr']['pyr_lvl_0'].fun_val))
+    n_calls[0] -= n_calls2
     losses.clear_engine_cache()
     return {'workload': f'{B} independent windows, pyramid 1..16, BFGS maxiter 40/28/19/11/8 + 1 retry at levels 0, 1, handover off',
             'batched': {'seconds': t_b, 'windows_per_s': B / t_b, 'engine_calls': calls_b, 'windows_evaluated': wins_b, 'staging_s': t_stage},
             'sequential': {'seconds_per_window': t_s / n_seq, 'windows_per_s': n_seq / t_s, 'engine_calls_per_window': n_calls[0] / n_seq,
                            'windows_timed': n_seq},
+            'sequential_rank2_update': {'seconds_per_window': t_s2 / n_seq, 'windows_per_s': n_seq / t_s2,
+                                        'engine_calls_per_window': n_calls2 / n_seq, 'windows_timed': n_seq},
             'speedup': (n_seq / t_s) and (B / t_b) / (n_seq / t_s),
-            'final_loss_level0': {'sequential': fin_s, 'batched_same_windows': fin_b, 'batched_mean_all_windows':
+            'speedup_over_sequential_rank2_update': (B / t_b) / (n_seq / t_s2),
+            'final_loss_level0': {'sequential': fin_s, 'sequential_rank2_update': fin_s2, 'batched_same_windows': fin_b, 'batched_mean_all_windows':
                                   float(np.mean([o['theta_opt_state_pyr']['pyr_lvl_0'].fun_val for o in out_b]))},
             'final_loss_note': 'the two drivers run the same algorithm; their end points differ where a line search fails on the fp32-level noise '
                                'of the objective (BFGS status 2 at the start of a level) - which of the two then makes progress is decided by '
                                'rounding (the reference itself needs float64 for this, configs/main.yaml:34).  tests/test_gpu_batch_solver.py '
                                'compares them on windows where both converge',
             'note': 'the batched driver restates SciPy BFGS with the O(n^2) form of the inverse-Hessian update above 64 unknowns; SciPy itself '
-                    'forms two n x n products per iteration (n = 512 at 16x16), which is most of the sequential time at the finest level'}
+                    'forms two n x n products per iteration (n = 512 at 16x16), which is most of the sequential time at the finest level: '
+                    'sequential_rank2_update is the one-window-at-a-time driver with that cost removed (solver params bfgs_update=rank2), '
+                    'i.e. what batching alone buys is speedup_over_sequential_rank2_update'}
 
 
 # =====================================================================================================================

@@ -94,7 +94,8 @@ class _CoroutineCall:
 class _WindowBFGS:
     """One window's BFGS, one function evaluation at a time (scipy.optimize._optimize._minimize_bfgs with jac=True)."""
 
-    def __init__(self, x0, maxiter, gtol, callback=None):
+    def __init__(self, x0, maxiter, gtol, callback=None, wolfe2_fallback=True):
+        self.wolfe2_fallback = bool(wolfe2_fallback)
         self.x0 = np.array(x0, dtype=np.float64).reshape(-1)
         self.n = self.x0.size
         self.maxiter = int(maxiter) if maxiter is not None else self.n * 200
@@ -169,6 +170,9 @@ class _WindowBFGS:
     def _ls_done(self, stp, single_eval):
         if stp is not None:
             return self._step_taken(stp, self.phi1, self.gval, single_eval)
+        if not self.wolfe2_fallback:                               # opt-out of SciPy's second line search: precision loss here and now
+            self.warnflag = 2
+            return self._finish()
         # _line_search_wolfe12: DCSRCH found no step, SciPy tries its other line search.  That one is not written for reverse
         # communication, so it runs in a helper thread whose f / fprime calls become this window's requests: the evaluations
         # stay in lockstep with the other windows (with the engine's fp32-level noise this fallback is the common end of a level)
@@ -252,17 +256,19 @@ class LockstepBFGS:
     fun_batch(X, mask) with X of shape (B, n) returns (values (B,), grads (B, n)); it is called once per tick with every window's
     current request (finished or inactive windows: their last point) and the mask of the windows that asked - the engine evaluates
     only those (Engine.loss_grad(active=...)), so a tick costs what its requesting windows cost.  ``active``: which windows are
-    minimised at all.
+    minimised at all.  ``wolfe2_fallback=False`` ends a minimisation with status 2 where DCSRCH finds no step, instead of trying SciPy's
+    second line search first (line_search_wolfe2: some 40 evaluations that rarely find a step once the first search has failed on the
+    objective's own roughness; profiles/r03/linesearch_fp64_vs_fp32.txt) - a deviation from SciPy, off by default.
     """
 
-    def __init__(self, fun_batch, x0, maxiter, gtol, callbacks=None, active=None):
+    def __init__(self, fun_batch, x0, maxiter, gtol, callbacks=None, active=None, wolfe2_fallback=True):
         x0 = np.asarray(x0, dtype=np.float64)
         self.B, self.n = x0.shape
         self.fun_batch = fun_batch
         act = np.ones(self.B, bool) if active is None else np.asarray(active, bool)
         maxiters = np.broadcast_to(np.asarray(maxiter), (self.B,))
         cbs = callbacks if callbacks is not None else [None] * self.B
-        self.windows = [(_WindowBFGS(x0[b], maxiters[b], gtol, cbs[b]) if act[b] else None) for b in range(self.B)]
+        self.windows = [(_WindowBFGS(x0[b], maxiters[b], gtol, cbs[b], wolfe2_fallback) if act[b] else None) for b in range(self.B)]
         self.last = x0.copy()
         self.n_batch_evals = 0                  # engine calls
         self.n_window_evals = 0                 # windows evaluated over all calls
@@ -409,7 +415,7 @@ class BatchedMultipleLevelEINCMSolver:
                     self.callbacks[b].reset_opt_iter()
             drv = LockstepBFGS(fun_batch, x, self.theta_opt_maxiters[key], gtol, callbacks=[
                 (lambda r, cb=self.callbacks[b], sh=shape: cb(spo.OptimizeResult(x=np.asarray(r.x).reshape(sh), fun=r.fun)))
-                for b in range(self.B)], active=active)
+                for b in range(self.B)], active=active, wolfe2_fallback=self.theta_opt_solver_params.get('wolfe2_fallback', True))
             res = drv.run()
             self.n_batch_evals += drv.n_batch_evals; self.n_window_evals += drv.n_window_evals
             for b in range(self.B):

@@ -29,9 +29,17 @@ class ScipyMinimize:
     """
 
     def __init__(self, fun, method=None, maxiter=500, jit=True, has_aux=False, options=None, callback=None, tol=None,
-                 dtype=np.float64, value_and_grad=True):
+                 dtype=np.float64, value_and_grad=True, bfgs_update='scipy', wolfe2_fallback=True):
+        """bfgs_update (method 'BFGS' only): 'scipy' = scipy.optimize.minimize itself; 'rank2' = the same algorithm restated in
+        batch_solver.LockstepBFGS, whose inverse-Hessian update costs O(n^2) instead of SciPy's two n x n products - identical iterates
+        up to 64 unknowns, equal to rounding beyond (at a 16x16 theta, n = 512, SciPy's update takes 10 ms per iteration, the
+        evaluation 0.1 ms)."""
         if not value_and_grad:
             raise ValueError('this wrapper needs fun to return (value, grad): the HIP engine cannot be differentiated by tracing')
+        if bfgs_update not in ('scipy', 'rank2'):
+            raise ValueError(f'bfgs_update {bfgs_update!r}: scipy or rank2')
+        self.bfgs_update = bfgs_update
+        self.wolfe2_fallback = bool(wolfe2_fallback)          # 'rank2' only: see batch_solver.LockstepBFGS
         self.fun, self.method, self.maxiter, self.has_aux = fun, method, int(maxiter), bool(has_aux)
         self.options = dict(options or {})
         self.callback, self.tol, self.dtype = callback, tol, dtype
@@ -60,9 +68,20 @@ class ScipyMinimize:
         x0 = np.asarray(init_params, dtype=self.dtype)
         shape = x0.shape
         self.num_fun_eval = 0
-        res = spo.minimize(self._scipy_fun(shape, args), x0.reshape(-1).astype(np.float64), jac=True, tol=self.tol,
-                           bounds=bounds, method=self.method, callback=self._scipy_callback(shape),
-                           options={**self.options, 'maxiter': self.maxiter})
+        if self.bfgs_update == 'rank2' and self.method == 'BFGS' and bounds is None:
+            from .batch_solver import LockstepBFGS          # (imports this module)
+            f = self._scipy_fun(shape, args)
+
+            def one(X, mask):
+                v, g = f(X[0])
+                return np.array([v]), g[None]
+            gtol = self.options.get('gtol', self.tol if self.tol is not None else 1e-5)
+            res = LockstepBFGS(one, x0.reshape(1, -1).astype(np.float64), self.maxiter, gtol,
+                               callbacks=[self._scipy_callback(shape)], wolfe2_fallback=self.wolfe2_fallback).run()[0]
+        else:
+            res = spo.minimize(self._scipy_fun(shape, args), x0.reshape(-1).astype(np.float64), jac=True, tol=self.tol,
+                               bounds=bounds, method=self.method, callback=self._scipy_callback(shape),
+                               options={**self.options, 'maxiter': self.maxiter})
         params = np.asarray(res.x, dtype=np.float64).reshape(shape)
         info = ScipyMinimizeInfo(fun_val=float(res.fun), success=bool(res.success), status=int(res.status),
                                  iter_num=int(res.nit), hess_inv=getattr(res, 'hess_inv', None),
@@ -235,7 +254,8 @@ class MultipleLevelEINCMSolver:
                 fun=partial(self.theta_loss_pfunc, cur_pyr_lvl=k), method=self.theta_opt_solver_params['method'],
                 maxiter=self.theta_opt_maxiters[key], jit=True, has_aux=True,
                 options={'gtol': self.theta_opt_solver_params['options']['gtol'], 'return_all': True},
-                callback=self.theta_solver_callback)
+                callback=self.theta_solver_callback, bfgs_update=self.theta_opt_solver_params.get('bfgs_update', 'scipy'),
+                wolfe2_fallback=self.theta_opt_solver_params.get('wolfe2_fallback', True))
             if self.handover_loss_pfunc is not None and self.handover_opt_solver_params is not None:
                 self.single_lvl_handover_solvers[key] = ScipyBoundedMinimize(
                     fun=partial(self.handover_loss_pfunc, cur_pyr_lvl=k), method=self.handover_opt_solver_params['method'],

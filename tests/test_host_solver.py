@@ -43,6 +43,35 @@ def test_scipy_minimize_wrapper_shape():
     assert a[0] == pytest.approx(1.0) and st.iter_num >= 1
 
 
+def test_rank_two_bfgs_option_takes_scipys_steps():
+    """bfgs_update='rank2': the sequential wrapper on batch_solver's restated BFGS - the same iterates as scipy.optimize.minimize up
+    to 64 unknowns (bit for bit), equal to rounding beyond, the same state fields and callback protocol."""
+    def rosen(x, scale):
+        x = x.reshape(-1)
+        f = scale * np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2)
+        g = np.zeros_like(x)
+        g[:-1] += scale * (-400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1]))
+        g[1:] += scale * 200.0 * (x[1:] - x[:-1] ** 2)
+        return (float(f), {}), g
+    for shape, exact in (((2, 3, 2), True), ((6, 8, 2), False)):
+        x0 = np.random.default_rng(5).uniform(-1, 1, shape)
+        out = {}
+        for upd in ('scipy', 'rank2'):
+            seen = []
+            s = sol.ScipyMinimize(fun=rosen, method='BFGS', maxiter=400, has_aux=True, options={'gtol': 1e-8, 'return_all': True},
+                                  callback=lambda ir: seen.append(ir.x.shape), bfgs_update=upd)
+            out[upd] = s.run(x0, 0.5) + (seen,)
+        (pa, sa, ca), (pb, sb, cb) = out['scipy'], out['rank2']
+        assert sa.success and sb.success and ca and all(c == shape for c in ca + cb)
+        if exact:
+            assert np.array_equal(pa, pb) and (sa.iter_num, sa.num_fun_eval, sa.status, sa.fun_val) == (sb.iter_num, sb.num_fun_eval, sb.status, sb.fun_val)
+            assert len(ca) == len(cb)
+        else:
+            assert np.abs(pa - pb).max() <= 1e-6 and abs(sa.iter_num - sb.iter_num) <= 0.05 * sa.iter_num      # (300+ iterations: roundings add up)
+    with pytest.raises(ValueError):
+        sol.ScipyMinimize(fun=rosen, method='BFGS', bfgs_update='other')
+
+
 def _oracle_pfuncs(H, W, alpha=20.0, beta=35.0, gamma=0.0):
     def vg(theta, xs, ys, ts, edges, edge_ts, cur_pyr_lvl):
         v, g, aux = O.loss_and_grad(theta, xs, ys, ts, edges, edge_ts, alpha, beta, gamma, 0.0, cur_pyr_lvl, 5, (H, W))
