@@ -22,7 +22,15 @@ from scipy.optimize._linesearch import line_search_wolfe2
 from scipy.linalg.blas import dsymv, dsyr2
 
 try:                                                 # level-2 BLAS on a 512 x 512 matrix must not fan out over the host's cores
-    from threadpoolctl import threadpool_limits      # (OpenBLAS with 8+ threads: 15 ms per dsyr2 instead of 0.1 ms)
+    import threadpoolctl                             # (OpenBLAS with 8+ threads: 15 ms per dsyr2 instead of 0.1 ms)
+    _TPC = [None]
+
+    def threadpool_limits(limits, user_api):
+        """threadpoolctl's limiter on ONE controller per process: building a controller walks every loaded shared library (2 ms
+        with torch in the process); limiting through an existing one takes 10 us."""
+        if _TPC[0] is None:
+            _TPC[0] = threadpoolctl.ThreadpoolController()
+        return _TPC[0].limit(limits=limits, user_api=user_api)
 except ImportError:                                  # without it the update stays in plain numpy
     threadpool_limits = None
 

@@ -480,6 +480,30 @@ def test_reference_shaped_callables():
     losses.clear_engine_cache()
 
 
+def test_engine_cache_notices_in_place_edits():
+    """losses.py keeps the staged window while the same array objects are passed; numpy arrays are mutable, so a content fingerprint
+    (256 strided samples per array) re-stages after an in-place edit of the events or the edges."""
+    H, W, R = 64, 96, 3
+    win = synth.make_window(61, (H, W), 6000, R, flow='constant', flow_mag=4.0)
+    a = [np.array(x) for x in win_args(win)]
+    th = synth.theta_near_truth(61, win, (1, 1))
+    call = lambda: losses.value_and_grad_loss_func(th, *a, 20.0, 35.0, 0.0, 0.0, 4, 5, (H, W))
+    (v0, _), g0 = call()
+    (v1, _), g1 = call()
+    assert v1 == v0 and np.array_equal(g0, g1) and len(losses._CACHE) == 1
+    eng0 = losses._CACHE[0][2]
+    a[2][:] = a[2][::-1].copy()                              # the same objects, other timestamps
+    (v2, _), g2 = call()
+    assert losses._CACHE[0][2] is not eng0 and v2 != v0
+    v_ref, g_ref, _ = O.loss_and_grad(th, *a, 20.0, 35.0, 0.0, 0.0, 4, 5, (H, W))
+    assert v2 == pytest.approx(v_ref, rel=TOL) and rel(g2, g_ref) <= TOL
+    a[3] *= 0.5                                              # edges edited in place
+    (v3, _), _ = call()
+    v_ref3, _, _ = O.loss_and_grad(th, *a, 20.0, 35.0, 0.0, 0.0, 4, 5, (H, W))
+    assert v3 == pytest.approx(v_ref3, rel=TOL) and v3 != v2
+    losses.clear_engine_cache()
+
+
 def test_warped_events_of_a_batch(monkeypatch):
     """eincm_get_warped_events: per window of a batch, caller's event order, 2-DoF theta (no Theta image until asked), a theta grid, and the
     host-binned staging path; bit for bit the oracle's per_pix_warp (event_warpers.py:28-37)."""
