@@ -21,6 +21,9 @@ from scipy.optimize._dcsrch import DCSRCH            # MINPACK-2 dcsrch as SciPy
 from scipy.optimize._linesearch import line_search_wolfe2
 from scipy.linalg.blas import dsymv, dsyr2
 
+if not hasattr(DCSRCH, '_iterate'):                  # private SciPy API (1.12 ... 1.15 have it): fail at import, not mid-solve
+    raise ImportError('batch_solver needs scipy.optimize._dcsrch.DCSRCH._iterate (SciPy >= 1.12); found SciPy ' + __import__('scipy').__version__)
+
 try:                                                 # level-2 BLAS on a 512 x 512 matrix must not fan out over the host's cores
     import threadpoolctl                             # (OpenBLAS with 8+ threads: 15 ms per dsyr2 instead of 0.1 ms)
     _TPC = [None]
@@ -41,6 +44,10 @@ _BFGS_C1, _BFGS_C2, _BFGS_XTOL, _BFGS_AMIN, _BFGS_AMAX, _LS_MAXITER = 1e-4, 0.9,
 _EXACT_UPDATE_MAX_N = 64          # up to this many unknowns the inverse-Hessian update is SciPy's own expression (two n x n products)
 
 
+class _Abandoned(BaseException):
+    """Raised inside a helper thread whose owner abandoned the minimisation."""
+
+
 class _CoroutineCall:
     """Runs target(f, fprime) in a helper thread and turns its calls of f(x) / fprime(x) into requests the owner answers:
     next() -> ('request', x) or ('done', result); answer(value, grad) resumes the target.  One of the two threads runs at a time."""
@@ -57,7 +64,9 @@ class _CoroutineCall:
             with self._cv:
                 self._req, self._state = x, 'waiting'
                 self._cv.notify_all()
-                self._cv.wait_for(lambda: self._state == 'running')
+                self._cv.wait_for(lambda: self._state in ('running', 'aborted'))
+                if self._state == 'aborted':
+                    raise _Abandoned()
                 v, g = self._ans
             self._cache = (x, g)
             return v
@@ -97,6 +106,15 @@ class _CoroutineCall:
             self._ans = (float(value), np.array(grad, dtype=np.float64).reshape(-1))
             self._state = 'running'
             self._cv.notify_all()
+
+    def abandon(self):
+        """The owner gives up (an evaluation raised): wake the helper with an exception so that its thread ends instead of waiting forever."""
+        with self._cv:
+            if self._state == 'done':
+                return
+            self._state = 'aborted'
+            self._cv.notify_all()
+        self._thread.join(timeout=5.0)
 
 
 class _WindowBFGS:
@@ -293,10 +311,16 @@ class LockstepBFGS:
 
     def run(self):
         """List of scipy OptimizeResult (None for inactive windows)."""
-        if threadpool_limits is not None:
-            with threadpool_limits(limits=1, user_api='blas'):
-                return self._run()
-        return self._run()
+        try:
+            if threadpool_limits is not None:
+                with threadpool_limits(limits=1, user_api='blas'):
+                    return self._run()
+            return self._run()
+        finally:                                   # an evaluation raised mid-solve: no helper thread of a line-search fallback stays behind
+            for w in self.windows:
+                ls2 = getattr(w, 'ls2', None) if w is not None else None
+                if ls2 is not None:
+                    ls2.abandon()
 
     def _run(self):
         while True:

@@ -124,3 +124,24 @@ def test_triangular_blas_update_equals_the_numpy_form(monkeypatch):
         assert np.abs(a.x - c.x).max() <= 1e-12 and np.abs(a.x - np.linalg.solve(A, b)).max() <= 1e-9
         assert np.array_equal(a.hess_inv, a.hess_inv.T)
         assert np.abs(a.hess_inv - c.hess_inv).max() <= 1e-9 * np.abs(c.hess_inv).max()
+
+
+def test_an_evaluation_error_leaves_no_helper_thread_behind():
+    """The wolfe2 fallback runs SciPy's function in a helper thread; if the batched evaluation raises while such a thread waits for
+    its answer, run() re-raises and the thread is woken and ended."""
+    import threading
+    funs = [noisy_quadratic(1, 6), noisy_quadratic(2, 6)]
+    x0 = np.random.default_rng(9).uniform(-1, 1, (2, 6))
+    drv_holder = {}
+
+    def fun_batch(X, mask):
+        drv = drv_holder['drv']
+        if any(w is not None and getattr(w, 'phase', '') == 'ls2' for w in drv.windows):
+            raise RuntimeError('engine failure')
+        vg = [funs[b](X[b]) for b in range(2)]
+        return np.array([v for v, _ in vg]), np.stack([g for _, g in vg])
+    before = threading.active_count()
+    drv_holder['drv'] = bs.LockstepBFGS(fun_batch, x0, 200, 1e-12)
+    with pytest.raises(RuntimeError, match='engine failure'):
+        drv_holder['drv'].run()
+    assert threading.active_count() == before
