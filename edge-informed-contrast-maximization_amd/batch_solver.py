@@ -287,10 +287,22 @@ class LockstepBFGS:
     objective's own roughness; profiles/r03/linesearch_fp64_vs_fp32.txt) - a deviation from SciPy, off by default.
     """
 
-    def __init__(self, fun_batch, x0, maxiter, gtol, callbacks=None, active=None, wolfe2_fallback=True):
+    def __init__(self, fun_batch, x0, maxiter, gtol, callbacks=None, active=None, wolfe2_fallback=True, groups=None, launch=None,
+                 collect=None):
+        """Pipelined form: ``groups`` (index arrays that partition the windows), ``launch(gi, X, mask)`` (enqueue the evaluation of group
+        gi's masked windows at X[groups[gi]] and return at once) and ``collect(gi)`` -> (values, grads) of that group.  While the host
+        advances the line searches of one group, the other groups' evaluations run on the GPU; ``fun_batch`` is not used then."""
         x0 = np.asarray(x0, dtype=np.float64)
         self.B, self.n = x0.shape
         self.fun_batch = fun_batch
+        self.groups = [np.asarray(ix, dtype=int) for ix in groups] if groups is not None else None
+        self.launch, self.collect = launch, collect
+        if self.groups is not None:
+            assert launch is not None and collect is not None
+            assert sorted(int(b) for ix in self.groups for b in ix) == list(range(self.B)), 'groups must partition the windows'
+            self._group_of = {int(b): gi for gi, ix in enumerate(self.groups) for b in ix}
+            self._pos = {int(b): i for ix in self.groups for i, b in enumerate(ix)}
+            self._inflight = [None] * len(self.groups)
         act = np.ones(self.B, bool) if active is None else np.asarray(active, bool)
         maxiters = np.broadcast_to(np.asarray(maxiter), (self.B,))
         cbs = callbacks if callbacks is not None else [None] * self.B
@@ -305,18 +317,32 @@ class LockstepBFGS:
             X[b] = np.asarray(x, dtype=np.float64).reshape(-1)
             m = np.zeros(self.B, bool); m[b] = True
             self.n_batch_evals += 1; self.n_window_evals += 1
+            if self.groups is not None:                 # (called while group gi is being fed: its context is idle)
+                gi = self._group_of[b]
+                self.launch(gi, X, m)
+                v, g = self.collect(gi)
+                return float(v[self._pos[b]]), np.array(g[self._pos[b]], dtype=np.float64)
             v, g = self.fun_batch(X, m)
             return float(v[b]), np.array(g[b], dtype=np.float64)
         return ev
 
     def run(self):
         """List of scipy OptimizeResult (None for inactive windows)."""
+        run = self._run if self.groups is None else self._run_pipelined
         try:
             if threadpool_limits is not None:
                 with threadpool_limits(limits=1, user_api='blas'):
-                    return self._run()
-            return self._run()
+                    return run()
+            return run()
         finally:                                   # an evaluation raised mid-solve: no helper thread of a line-search fallback stays behind
+            if self.groups is not None:            # ... and no evaluation in flight
+                for gi, req in enumerate(self._inflight):
+                    if req is not None:
+                        self._inflight[gi] = None
+                        try:
+                            self.collect(gi)
+                        except Exception:          # noqa: BLE001 - the first error is the one that propagates
+                            pass
             for w in self.windows:
                 ls2 = getattr(w, 'ls2', None) if w is not None else None
                 if ls2 is not None:
@@ -335,10 +361,41 @@ class LockstepBFGS:
             v, g = self.fun_batch(self.last, m)
             for b, w in req:
                 w.feed(v[b], g[b], self._single(b))
+        return self._results()
+
+    def _results(self):
         for b, w in enumerate(self.windows):          # riders keep their final point in `last`
             if w is not None:
                 self.last[b] = w.result.x
         return [w.result if w is not None else None for w in self.windows]
+
+    def _start_group(self, gi):
+        req = [(int(b), self.windows[b]) for b in self.groups[gi] if self.windows[b] is not None and self.windows[b].request is not None]
+        if not req:
+            self._inflight[gi] = None
+            return
+        m = np.zeros(self.B, bool)
+        for b, w in req:
+            self.last[b] = w.request
+            m[b] = True
+        self.n_batch_evals += 1; self.n_window_evals += len(req)
+        self.launch(gi, self.last, m)
+        self._inflight[gi] = req
+
+    def _run_pipelined(self):
+        for gi in range(len(self.groups)):
+            self._start_group(gi)
+        while any(r is not None for r in self._inflight):
+            for gi in range(len(self.groups)):
+                req = self._inflight[gi]
+                if req is None:
+                    continue
+                v, g = self.collect(gi)                # waits for group gi; the other groups' evaluations keep running
+                self._inflight[gi] = None
+                for b, w in req:
+                    w.feed(v[self._pos[b]], g[self._pos[b]], self._single(b))
+                self._start_group(gi)                  # back on the GPU before the next group is collected and fed
+        return self._results()
 
 
 def _info(res):
@@ -348,7 +405,7 @@ def _info(res):
 
 
 class BatchedMultipleLevelEINCMSolver:
-    """The coarse-to-fine theta pyramid of B windows, solved level by level in lockstep on ONE engine context.
+    """The coarse-to-fine theta pyramid of B windows, solved level by level in lockstep on one engine context (or ``n_groups`` of them).
 
     Constructor keywords follow ``solver.MultipleLevelEINCMSolver`` (reference solver.py:16-126); instead of loss callables it
     takes the loss parameters (``loss_kwargs``: alpha, beta, gamma, delta, scale_to_sensor_size_method[, contrast_kind]), because
@@ -360,7 +417,9 @@ class BatchedMultipleLevelEINCMSolver:
     def __init__(self, n_windows, sensor_size, n_pyr_lvls, theta_opt_maxiters, loss_kwargs, theta_opt_solver_params,
                  handover_opt_maxiters=None, handover_opt_solver_params=None, handover_settings=None,
                  pyramid_downscale_method='bilinear', pyramid_upscale_method='repeat', pyramid_bases=None, device=0,
-                 theta_solver_callbacks=None):
+                 theta_solver_callbacks=None, n_groups=1):
+        """n_groups > 1: the windows are split over that many engine contexts (HIP streams) and the lockstep is pipelined - while the
+        host advances one group's line searches the other groups' evaluations run (LockstepBFGS, pipelined form)."""
         hs = handover_settings
         if hs is None:
             hs = {'use_handover': False, 'solve_handover_for_levels': [], 'use_downscaled_finest_priors': False,
@@ -379,7 +438,10 @@ class BatchedMultipleLevelEINCMSolver:
         self.pyramid_bases = pyramid_bases if pyramid_bases is not None else [2] * (n_pyr_lvls - 1)
         self.callbacks = theta_solver_callbacks if theta_solver_callbacks is not None else [EmptyCallback() for _ in range(self.B)]
         self.device = device
-        self.engine = None
+        self.n_groups = max(1, min(int(n_groups), self.B))
+        self.groups = [np.asarray(ix, dtype=int) for ix in np.array_split(np.arange(self.B), self.n_groups)]
+        self.engines = []
+        self.engine = None                      # the first group's context (the only one when n_groups == 1)
         self._first = True
         top = np.zeros((1, 1, 2))
         self.prior = [self._pyramid_from_top(top) for _ in range(self.B)]        # prior_theta_pyr per window
@@ -407,19 +469,20 @@ class BatchedMultipleLevelEINCMSolver:
     def set_datasamples(self, windows):
         """windows: B tuples (xs, ys, ts, edges, edge_ts)."""
         assert len(windows) == self.B
-        n_tot = sum(len(w[0]) for w in windows)
+        n_tot = max(sum(len(windows[b][0]) for b in ix) for ix in self.groups)
         R = len(np.atleast_1d(windows[0][4]))
-        if self.engine is None or n_tot > self._cap or R > self._cap_r:
-            if self.engine is not None:
-                self.engine.close()
+        if not self.engines or n_tot > self._cap or R > self._cap_r:
+            self.close()
             self._cap, self._cap_r = max(n_tot, 1), R
-            self.engine = Engine(self.sensor_size, self._cap, max_refs=R, max_windows=self.B, device=self.device)
-        self.engine.set_windows(list(windows))
+            self.engines = [Engine(self.sensor_size, self._cap, max_refs=R, max_windows=len(ix), device=self.device) for ix in self.groups]
+            self.engine = self.engines[0]
+        for eng, ix in zip(self.engines, self.groups):
+            eng.set_windows([windows[b] for b in ix])
 
     def close(self):
-        if self.engine is not None:
-            self.engine.close()
-            self.engine = None
+        for eng in self.engines:
+            eng.close()
+        self.engines, self.engine = [], None
 
     def _params(self, lvl):
         kw = self.loss_kwargs
@@ -435,6 +498,15 @@ class BatchedMultipleLevelEINCMSolver:
         def fun_batch(X, mask):
             v, g, _ = self.engine.loss_grad(X.reshape((self.B,) + shape), p, active=mask)
             return v, g.reshape(self.B, -1)
+
+        def launch(gi, X, mask):
+            ix = self.groups[gi]
+            self.engines[gi].loss_grad_async(X[ix].reshape((len(ix),) + shape), p, active=mask[ix])
+
+        def collect(gi):
+            v, g, _ = self.engines[gi].loss_grad_wait()
+            return v, g.reshape(len(self.groups[gi]), -1)
+        pipe = dict(groups=self.groups, launch=launch, collect=collect) if self.n_groups > 1 else {}
         gtol = self.theta_opt_solver_params['options']['gtol']
         extra = (self.theta_opt_solver_params.get('n_extra_attempts', {}) or {}).get(key, 0)
         x = np.stack([np.asarray(s, dtype=np.float64).reshape(-1) for s in starts])
@@ -447,7 +519,7 @@ class BatchedMultipleLevelEINCMSolver:
                     self.callbacks[b].reset_opt_iter()
             drv = LockstepBFGS(fun_batch, x, self.theta_opt_maxiters[key], gtol, callbacks=[
                 (lambda r, cb=self.callbacks[b], sh=shape: cb(spo.OptimizeResult(x=np.asarray(r.x).reshape(sh), fun=r.fun)))
-                for b in range(self.B)], active=active, wolfe2_fallback=self.theta_opt_solver_params.get('wolfe2_fallback', True))
+                for b in range(self.B)], active=active, wolfe2_fallback=self.theta_opt_solver_params.get('wolfe2_fallback', True), **pipe)
             res = drv.run()
             self.n_batch_evals += drv.n_batch_evals; self.n_window_evals += drv.n_window_evals
             for b in range(self.B):
@@ -479,8 +551,12 @@ class BatchedMultipleLevelEINCMSolver:
                 def f(a, b=b):
                     aa = a_cur.copy(); aa[b] = float(np.asarray(a).reshape(-1)[0])
                     self.n_batch_evals += 1
-                    v, dv = self.engine.handover_loss_grad(aa, np.stack(priors), np.stack(thetas), p, want_grad=True)
-                    return float(v[b]), np.array([dv[b]])
+                    gi = next(g for g, ix in enumerate(self.groups) if b in ix)      # the window's own context; its group rides along
+                    ix = self.groups[gi]
+                    v, dv = self.engines[gi].handover_loss_grad(aa[ix], np.stack([priors[i] for i in ix]),
+                                                                np.stack([thetas[i] for i in ix]), p, want_grad=True)
+                    k_loc = int(np.where(ix == b)[0][0])
+                    return float(v[k_loc]), np.array([dv[k_loc]])
                 r = spo.minimize(f, np.array([0.5]), jac=True, method=self.handover_opt_solver_params['method'],
                                  bounds=spo.Bounds([limits[0]], [limits[1]]),
                                  options={'gtol': self.handover_opt_solver_params['options']['gtol'],

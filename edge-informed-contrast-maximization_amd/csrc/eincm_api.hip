@@ -1792,6 +1792,10 @@ int eincm_mask_device_ptr(eincm_ctx* c, void** dptr, int64_t* n_bytes) {
 }
 
 int eincm_loss_grad_async(eincm_ctx* c, const double* theta, int h, int w, const eincm_params* p, int want_grad) {
+    return eincm_loss_grad_masked_async(c, theta, h, w, p, nullptr, want_grad);
+}
+
+int eincm_loss_grad_masked_async(eincm_ctx* c, const double* theta, int h, int w, const eincm_params* p, const uint8_t* active, int want_grad) {
     if (!c) return EINCM_ERR_ARG;
     if (!c->staged) return fail(c, EINCM_ERR_STATE, "eincm_loss_grad_async called before eincm_set_windows");
     if (c->constants_pending) return fail(c, EINCM_ERR_STATE, "window constants are not finished (eincm_finish_constants)");
@@ -1799,7 +1803,7 @@ int eincm_loss_grad_async(eincm_ctx* c, const double* theta, int h, int w, const
     if (h < 1 || w < 1) return fail(c, EINCM_ERR_ARG, "theta shape (%d,%d,2) invalid", h, w);
     if (p->method < 0 || p->method > EINCM_METHOD_CUBIC) return fail(c, EINCM_ERR_ARG, "method %d unknown", p->method);
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = eval_begin(c, theta, h, w, p, want_grad != 0);
+    int rc = eval_begin(c, theta, h, w, p, want_grad != 0, active);
     if (rc) return rc;
     rc = eval_end_launch(c);
     if (rc) { (void)hipStreamSynchronize(c->stream); c->pend.active = false; c->pend.launched = false; }

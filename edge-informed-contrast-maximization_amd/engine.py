@@ -175,15 +175,21 @@ class Engine:
         return value, grad, auxl
 
     # -- asynchronous evaluation: enqueue now, collect later (several contexts in flight, see EngineGroup) ----
-    def loss_grad_async(self, theta, params, want_grad=True):
+    def loss_grad_async(self, theta, params, want_grad=True, active=None):
+        """Enqueue an evaluation and return at once (theta is copied before the call returns); ``active`` as in loss_grad."""
         th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64))
         if th.ndim == 3:
             th = th[None]
         if th.ndim != 4 or th.shape[0] != self.B or th.shape[3] != 2:
             raise ValueError(f'theta must be ({self.B},h,w,2), got {th.shape}')
+        act = None
+        if active is not None:
+            act = np.ascontiguousarray(np.asarray(active).astype(np.uint8))
+            if act.shape != (self.B,):
+                raise ValueError(f'active must be ({self.B},), got {act.shape}')
         self._async = None
-        self._check(self._lib.eincm_loss_grad_async(self._ctx, th.ctypes.data, th.shape[1], th.shape[2], C.byref(params),
-                                                    1 if want_grad else 0))
+        self._check(self._lib.eincm_loss_grad_masked_async(self._ctx, th.ctypes.data, th.shape[1], th.shape[2], C.byref(params),
+                                                           act.ctypes.data if act is not None else None, 1 if want_grad else 0))
         self._async = (th.shape, bool(want_grad))
 
     def loss_grad_wait(self, want_aux=False, allow_nonfinite=True):

@@ -25,7 +25,7 @@ extern "C" {
 
 #define EINCM_ABI_VERSION 5   /* 2: eincm_iwe_device_ptr hands out the u64 fixed-point accumulator of the IWE stack; 3: eincm_set_timed_kernels, eincm_set_windows_ptrs;
                                 * 4: eincm_loss_grad_masked, eincm_set_device_results / eincm_finish_launch / eincm_grad_device_ptr / eincm_finish_collect, eincm_get_host_profile;
-                               * 5: eincm_get_warped_events, eincm_loss_grad_device */
+                               * 5: eincm_get_warped_events, eincm_loss_grad_device, eincm_loss_grad_masked_async */
 
 #define EINCM_OK               0
 #define EINCM_ERR_ARG         -1   /* bad argument (shape, null pointer, out-of-range event coordinate) */
@@ -175,6 +175,9 @@ int eincm_loss_grad_wait(eincm_ctx* ctx, double* value, double* grad, eincm_aux*
  * at a time, src/eincm/solver.py:209-216).  Windows beyond the 64th are always evaluated. */
 int eincm_loss_grad_masked(eincm_ctx* ctx, const double* theta, int h, int w, const eincm_params* p, const uint8_t* active,
                            double* value, double* grad, eincm_aux* aux);
+/* ... and its asynchronous form (collected by eincm_loss_grad_wait): a lockstep solver that drives two contexts keeps the GPU busy with
+ * one group of windows while the host advances the other group's line searches */
+int eincm_loss_grad_masked_async(eincm_ctx* ctx, const double* theta, int h, int w, const eincm_params* p, const uint8_t* active, int want_grad);
 
 /* handover_loss_func (losses.py:208-276) and d/d(alpha_handover) = <dL/dtheta_ho, prev - theta>:
  *   theta_ho = a*prev_theta + (1-a)*theta;  a (n_windows), value (n_windows), dvalue_da (n_windows) or NULL */

@@ -44,7 +44,7 @@ def sequential_solver(H, W, n_lvls, maxiter, hs):
         handover_settings=hs, pyramid_downscale_method='lanczos3', pyramid_upscale_method='repeat', pyramid_bases=[2] * (n_lvls - 1))
 
 
-def batched_solver(B, H, W, n_lvls, maxiter, hs):
+def batched_solver(B, H, W, n_lvls, maxiter, hs, n_groups=1):
     return bsol.BatchedMultipleLevelEINCMSolver(
         B, (H, W), n_lvls, sol.growing_maxiters(n_lvls, maxiter / 5, maxiter), LOSS,
         {'method': 'BFGS', 'options': {'gtol': 1e-7}, 'n_extra_attempts': {'pyr_lvl_0': 1, 'pyr_lvl_1': 1}},
@@ -52,14 +52,15 @@ def batched_solver(B, H, W, n_lvls, maxiter, hs):
         handover_settings=hs, pyramid_downscale_method='lanczos3', pyramid_upscale_method='repeat', pyramid_bases=[2] * (n_lvls - 1))
 
 
-def test_eight_windows_in_lockstep_reach_the_sequential_optima():
+@pytest.mark.parametrize('n_groups', [1, 2])
+def test_eight_windows_in_lockstep_reach_the_sequential_optima(n_groups):
     """8 independent windows, pyramid 1 -> 2 -> 4: the batched solve ends where 8 sequential solves end (the tolerance of
     test_hip_and_oracle_backends_agree_on_a_small_solve: objective 1e-4 relative, theta 0.05 px), window by window and level by level,
     with a fraction of the engine calls."""
     B, H, W, N, R, n_lvls = 8, 96, 128, 12000, 3, 3
     wins = [synth.make_window(60 + b, (H, W), N, R, flow='constant', flow_mag=3.0 + 0.5 * b) for b in range(B)]
     args = [(w['xs'], w['ys'], w['ts'], w['edges'], w['edge_ts']) for w in wins]
-    bs = batched_solver(B, H, W, n_lvls, 16, None)
+    bs = batched_solver(B, H, W, n_lvls, 16, None, n_groups)          # n_groups = 2: two contexts, pipelined lockstep
     bs.set_datasamples(args)
     out_b = bs.solve()
     N_SEQ_CALLS[0] = 0
@@ -80,18 +81,19 @@ def test_eight_windows_in_lockstep_reach_the_sequential_optima():
     # lockstep: one engine call per tick serves every window that asked (the others are masked out of the call), so the batch needs far
     # fewer calls than the sequential solves and evaluates no more windows than they do (plus nothing for the riders)
     n_seq_evals = N_SEQ_CALLS[0]
-    assert bs.n_batch_evals < 0.5 * n_seq_evals, (bs.n_batch_evals, n_seq_evals)
+    assert bs.n_batch_evals < (0.5 if n_groups == 1 else 0.8) * n_seq_evals, (bs.n_batch_evals, n_seq_evals)
     assert bs.n_window_evals <= 1.3 * n_seq_evals, (bs.n_window_evals, n_seq_evals)      # (failing line searches end after different counts)
     print(f'engine calls: batched {bs.n_batch_evals}, sequential {n_seq_evals}; windows evaluated: batched {bs.n_window_evals}')
 
 
-def test_two_sequences_with_handover():
+@pytest.mark.parametrize('n_groups', [1, 2])
+def test_two_sequences_with_handover(n_groups):
     """B independent sequences: the second solve of every sequence hands over from its own first solve (solved weights at levels 1, 0
     like the reference's defaults), and agrees with the sequential solver run on that sequence alone."""
     B, H, W, N, R, n_lvls = 2, 96, 128, 8000, 3, 3
     seqs = [[synth.make_window(70 + 10 * b + i, (H, W), N, R, flow='constant', flow_mag=4.0 + b) for i in range(2)] for b in range(B)]
     tup = lambda w: (w['xs'], w['ys'], w['ts'], w['edges'], w['edge_ts'])
-    bs = batched_solver(B, H, W, n_lvls, 10, HS)
+    bs = batched_solver(B, H, W, n_lvls, 10, HS, n_groups)
     outs = []
     for i in range(2):
         bs.set_datasamples([tup(seqs[b][i]) for b in range(B)])

@@ -145,3 +145,33 @@ def test_an_evaluation_error_leaves_no_helper_thread_behind():
     with pytest.raises(RuntimeError, match='engine failure'):
         drv_holder['drv'].run()
     assert threading.active_count() == before
+
+
+@pytest.mark.parametrize('groups', [[[0, 1], [2, 3]], [[2], [0, 3], [1]]])
+def test_pipelined_groups_take_the_same_steps(groups):
+    """The pipelined form (several evaluation contexts, launch / collect) only changes WHEN a window is evaluated: every window's
+    iterates, counts and status equal the plain lockstep's and SciPy's."""
+    n = 10
+    funs = [rosen_like(s) for s in (1.0, 0.3, 2.5, 1e-2)]
+    x0 = np.random.default_rng(3).uniform(-1.5, 1.5, (4, n))
+    res, ref, _ = run_pair(funs, x0, maxiter=60, gtol=1e-7)
+    pending, log = {}, []
+
+    def launch(gi, X, mask):
+        assert gi not in pending                                   # one evaluation in flight per context
+        ix = groups[gi]
+        assert not mask[[b for b in range(4) if b not in ix]].any()
+        pending[gi] = [(funs[b](X[b]) if mask[b] else (np.nan, np.zeros(n))) for b in ix]
+        log.append(('launch', gi))
+
+    def collect(gi):
+        vg = pending.pop(gi)
+        log.append(('collect', gi))
+        return np.array([v for v, _ in vg]), np.stack([g for _, g in vg])
+    drv = bs.LockstepBFGS(None, x0, 60, 1e-7, groups=groups, launch=launch, collect=collect)
+    out = drv.run()
+    assert not pending
+    for a, b, c in zip(out, res, ref):
+        assert np.array_equal(a.x, b.x) and np.array_equal(a.x, c.x) and (a.nit, a.nfev, a.status) == (c.nit, c.nfev, c.status)
+    # every group is launched before the first one is collected: their evaluations overlap
+    assert [e for e in log[:len(groups)]] == [('launch', gi) for gi in range(len(groups))]
