@@ -44,6 +44,37 @@ _BFGS_C1, _BFGS_C2, _BFGS_XTOL, _BFGS_AMIN, _BFGS_AMAX, _LS_MAXITER = 1e-4, 0.9,
 _EXACT_UPDATE_MAX_N = 64          # up to this many unknowns the inverse-Hessian update is SciPy's own expression (two n x n products)
 
 
+class _QuietLineSearch:
+    """``warnings.catch_warnings`` is process-wide state: helper threads that enter and leave it independently restore each other's
+    filters (the first one out switches the warning back on for the others).  This one counts: the first thread in installs the
+    filter for scipy's LineSearchWarning, the last one out restores what was there."""
+
+    def __init__(self):
+        import threading
+        self._lock, self._n, self._cw = threading.Lock(), 0, None
+
+    def __enter__(self):
+        import warnings
+        from scipy.optimize._linesearch import LineSearchWarning
+        with self._lock:
+            if self._n == 0:
+                self._cw = warnings.catch_warnings()
+                self._cw.__enter__()
+                warnings.simplefilter('ignore', LineSearchWarning)
+            self._n += 1
+
+    def __exit__(self, *exc):
+        with self._lock:
+            self._n -= 1
+            if self._n == 0:
+                self._cw.__exit__(None, None, None)
+                self._cw = None
+        return False
+
+
+_quiet_line_search = _QuietLineSearch()
+
+
 class _Abandoned(BaseException):
     """Raised inside a helper thread whose owner abandoned the minimisation."""
 
@@ -78,10 +109,8 @@ class _CoroutineCall:
             return self._cache[1]
 
         def run():
-            import warnings
             try:
-                with warnings.catch_warnings():                 # (SciPy's BFGS silences the fallback's LineSearchWarning the same way)
-                    warnings.simplefilter('ignore')
+                with _quiet_line_search:                        # (SciPy's BFGS silences the fallback's LineSearchWarning too)
                     res = target(f, fp)
             except BaseException as e:          # noqa: BLE001 - handed to the owner
                 res = e

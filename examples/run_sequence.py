@@ -39,6 +39,9 @@ def main():
     ap.add_argument('--windows', type=int, default=3)
     ap.add_argument('--refs', type=int, default=5)
     ap.add_argument('--flow-mag', type=float, default=4.0)
+    ap.add_argument('--sequences', type=int, default=1,
+                    help='> 1: that many independent sequences side by side on the lockstep batch solver (one masked engine call per tick)')
+    ap.add_argument('--rank2', action='store_true', help="sequential driver with the O(n^2) BFGS update (theta_opt_solver_params['bfgs_update'] = 'rank2')")
     ap.add_argument('overrides', nargs='*')
     a = ap.parse_args()
     cfg = config.load_config(a.config_dir, 'main', a.overrides) if a.config_dir else config._wrap(DEFAULTS)
@@ -47,6 +50,10 @@ def main():
     kw = dict(alpha=cfg.alpha, beta=cfg.beta, gamma=cfg.gamma, delta=cfg.delta, n_pyr_lvls=n_lvls, sensor_size=(H, W),
               scale_to_sensor_size_method=cfg.scale_theta_to_sensor_size_method)
     sp = cfg.solver_params
+    if a.sequences > 1:
+        return run_batched(a, cfg, H, W, n_lvls)
+    if a.rank2:
+        sp.theta_opt['bfgs_update'] = 'rank2'
     cb = sol.CollectingCallback()
     solver = sol.MultipleLevelEINCMSolver(
         n_pyr_lvls=n_lvls,
@@ -82,6 +89,51 @@ def main():
         scores.append((ev['fwl'], ev['AEE'], t_solve))
     s = np.array(scores)
     print(f'mean FWL {s[:,0].mean():.4f}  mean AEE {s[:,1].mean():.3f}  mean solve time {s[:,2].mean()*1e3:.1f} ms/window')
+    losses.clear_engine_cache()
+
+
+def stage_window(cfg, seed, i, refs, flow_mag, H, W):
+    """One "loader" sample of a sequence, staged like exp_mgr does (time-normalised, fitted to des_n_events)."""
+    win = synth.make_window(seed, (H, W), int(cfg.des_n_events * 1.3), refs, flow='constant', flow_mag=flow_mag)
+    t_us = 1_000_000.0 * (i + win['ts'])
+    sl, _ = staging.select_events(t_us, 1_000_000.0 * i, 1_000_000.0 * (i + 1), cfg.des_n_events, True)
+    sample = {'events': {'x': win['xs'][sl], 'y': win['ys'][sl], 't': t_us[sl]},
+              'image_ts': 1_000_000.0 * (i + win['edge_ts']), 'eval_ts_us': (1_000_000.0 * i, 1_000_000.0 * (i + 1))}
+    return staging.stage_datasample(sample, win['edges']), win
+
+
+def run_batched(a, cfg, H, W, n_lvls):
+    """B sequences advance together: window i of every sequence is solved in one lockstep pyramid solve, each sequence handing over
+    from its own previous window (batch_solver.BatchedMultipleLevelEINCMSolver; two engine contexts, pipelined)."""
+    from eincm_amd import batch_solver as bsol
+    B, sp = a.sequences, cfg.solver_params
+    loss = dict(alpha=cfg.alpha, beta=cfg.beta, gamma=cfg.gamma, delta=cfg.delta, scale_to_sensor_size_method=cfg.scale_theta_to_sensor_size_method)
+    bs = bsol.BatchedMultipleLevelEINCMSolver(
+        B, (H, W), n_lvls,
+        sol.growing_maxiters(n_lvls, sp.theta_opt.miniter, sp.theta_opt.maxiter, cfg.maxiters_grow_order, cfg.use_growing_maxiters), loss,
+        dict(sp.theta_opt),
+        handover_opt_maxiters=sol.growing_maxiters(n_lvls, sp.handover_opt.miniter, sp.handover_opt.maxiter, cfg.maxiters_grow_order, cfg.use_growing_maxiters),
+        handover_opt_solver_params=dict(sp.handover_opt), handover_settings=dict(cfg.handover_settings),
+        pyramid_downscale_method=cfg.pyramid_downscale_method, pyramid_upscale_method=cfg.pyramid_upscale_method,
+        pyramid_bases=list(cfg.pyramid_bases), n_groups=min(2, B))
+    print(f'{B} sequences side by side, sensor {H}x{W}, {cfg.des_n_events} events/window, R={a.refs}')
+    scores = []
+    for i in range(a.windows):
+        staged = [stage_window(cfg, 900 + 100 * b + i, i, a.refs, a.flow_mag + 0.5 * b, H, W) for b in range(B)]
+        bs.set_datasamples([st for st, _ in staged])
+        t0 = time.perf_counter()
+        outs = bs.solve()
+        t_solve = time.perf_counter() - t0
+        for b, ((xs, ys, ts, edges, edge_ts), win) in enumerate(staged):
+            Theta = sol.rescale_theta(outs[b]['final_theta_pyr']['pyr_lvl_0'], (H, W), 'bilinear')
+            ev, _ = evaluation.evaluate_theta_array(Theta, xs, ys, ts, edges, edge_ts, win['flow_gt'], cfg.alpha, cfg.beta, cfg.gamma, cfg.delta,
+                                                    (H, W), evaluation.make_event_mask(xs, ys, (H, W)))
+            scores.append((ev['fwl'], ev['AEE']))
+            print(f'window {i} of sequence {b}: loss {ev["loss"]:.4f} FWL {ev["fwl"]:.4f} AEE {ev["AEE"]:.3f}')
+        print(f'window {i}: {B} windows solved in {t_solve * 1e3:.1f} ms ({bs.n_batch_evals} engine calls so far)')
+    bs.close()
+    s = np.array(scores)
+    print(f'mean FWL {s[:, 0].mean():.4f}  mean AEE {s[:, 1].mean():.3f}')
     losses.clear_engine_cache()
 
 

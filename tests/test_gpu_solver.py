@@ -109,3 +109,7 @@ def test_example_sequence_script_runs():
                        text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert 'window 1:' in r.stdout and 'solved handover weights' in r.stdout and 'mean FWL' in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, 'examples', 'run_sequence.py'), '--windows', '2', '--sequences', '3'],
+                       capture_output=True, text=True, timeout=300)          # three sequences side by side on the lockstep batch solver
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'window 1 of sequence 2:' in r.stdout and 'mean FWL' in r.stdout
