@@ -11,7 +11,7 @@
  *   - all host arrays are C-order (row major), caller-owned; nothing is retained after a call returns
  *   - theta / grad / value / ts / edges / edge_ts are double (the SciPy side of the reference is float64,
  *     SURVEY 8b); x, y are int16 (the reference's event wire format, exp_mgr.py:283-284)
- *   - a context is NOT thread-safe; one context per (GPU, caller thread); every call is synchronous
+ *   - a context is NOT thread-safe; one context per (GPU, caller thread); every call is synchronous except the *_async forms
  *   - return value: 0 = ok, < 0 = error (see EINCM_ERR_*); eincm_last_error() gives the message
  */
 #ifndef EINCM_H
@@ -53,7 +53,7 @@ extern "C" {
 
 /* eincm_create flags */
 #define EINCM_CF_TIMING     1u     /* every stage timed with HIP events (eincm_get_timings): attached to the launch where a stage is one
-                                     * kernel, marker events otherwise and around the whole evaluation; costs ~13 % of a step */
+                                     * kernel, marker events otherwise and around the whole evaluation; costs ~10 % of a step */
 #define EINCM_CF_TIMING_DOMINANT 2u /* the two event kernels (k_splat, k_gather) are launched with their own start / stop events
                                      * (hipExtLaunchKernelGGL: no marker packets on the stream) and the events are read when the
                                      * timings are asked for, not after every evaluation; total_ms stays 0 in this mode.
@@ -163,9 +163,10 @@ int eincm_loss_grad(eincm_ctx* ctx, const double* theta, int h, int w, const ein
 
 /* Asynchronous form of eincm_loss_grad: _async copies theta, enqueues the whole evaluation on the context's stream and returns;
  * _wait synchronises that stream and hands over (value, grad, aux) exactly as eincm_loss_grad does.  One host thread can keep
- * several contexts in flight this way (one HIP stream each): the small, latency-bound kernels of one context then run beside
- * the event kernels of another (+18 % / +25 % throughput with 2 / 4 contexts on the 8-window batch).  No other call on the
- * context is allowed between the two. */
+ * several contexts in flight this way (one HIP stream each): the host's work for one context (e.g. a solver's line-search bookkeeping)
+ * overlaps another context's kernels - the pipelined lockstep solver runs 8 pyramid solves in 0.18 s instead of 0.24 s on two contexts.
+ * (Evaluation throughput alone does not gain since round 2: both event kernels are throughput-bound)  No other
+ * call on the context is allowed between the two. */
 int eincm_loss_grad_async(eincm_ctx* ctx, const double* theta, int h, int w, const eincm_params* p, int want_grad);
 int eincm_loss_grad_wait(eincm_ctx* ctx, double* value, double* grad, eincm_aux* aux);
 
