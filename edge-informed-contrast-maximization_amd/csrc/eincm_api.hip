@@ -445,7 +445,7 @@ int clear_accumulators(eincm_ctx* c) {
 
 // theta -> Theta image (+ per-tile velocity bounds) for every window.  theta_dev: (B,h,w,2) on the device or in mapped host memory.
 // with_windows: k_theta also fills the window tables of both segment lists (every theta but the 2-DoF one, whose k_theta_const does)
-void launch_theta_image(eincm_ctx* c, int h, int w, bool identity, bool use_arg, const ThetaArg& targ, const double* theta_dev,
+void launch_theta_image(eincm_ctx* c, int h, int w, bool identity, bool use_arg, const ThetaArgBig& targ, const double* theta_dev,
                         bool with_windows) {
     const Geom& g = c->g;
     const bool ww = with_windows && c->itembase_valid;
@@ -465,11 +465,18 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
     const bool const_theta = !identity && h == 1 && w == 1;
     const double* theta_dev = c->d_theta_in;
     ThetaArg targ;
+    // k_theta alone takes a larger theta in its own arguments (a 16x16 grid of one window: 4 KiB); the event kernels read the Theta image
+    static const bool no_big_arg = getenv("EINCM_NO_BIG_THETA_ARG") != nullptr;
+    const bool use_arg_big = !c->theta_dev_in && !identity && (size_t)g.B * nth <= (size_t)THETA_ARG_BIG && !no_big_arg;
+    static thread_local ThetaArgBig targ_big;
+    if (use_arg_big) memcpy(targ_big.v, theta_host, (size_t)g.B * nth * sizeof(double));
     if (c->theta_dev_in) {
         theta_dev = c->theta_dev_in;                 // device-resident theta: the kernels read the caller's buffer, nothing crosses PCIe
         if (const_theta) need_theta_image = true;    // (no host copy of theta for ensure_theta_image to rebuild the image from)
     } else if (use_arg) {
         memcpy(targ.v, theta_host, (size_t)g.B * nth * sizeof(double));     // theta rides in the kernel arguments
+    } else if (use_arg_big) {
+        theta_dev = c->h_theta;                      // (not read: k_theta has theta in its arguments)
     } else if ((size_t)g.B * nth <= ZERO_COPY_MAX) {
         // medium theta (e.g. 16x16): k_theta reads it straight from the pinned, GPU-mapped staging buffer (no copy command)
         memcpy(c->h_theta, theta_host, (size_t)g.B * nth * sizeof(double));
@@ -492,7 +499,7 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
         if (const_theta) {
             if (theta_host) c->last_theta11.assign(theta_host, theta_host + (size_t)g.B * 2); else c->last_theta11.clear();
             c->Theta_valid = false;
-            if (need_theta_image) launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev, false);
+            if (need_theta_image) launch_theta_image(c, h, w, identity, use_arg_big, targ_big, theta_dev, false);
             // the event kernels derive their windows from theta themselves; the velocity bounds (tmm) only feed k_final's NaN scan,
             // which a host-assembled evaluation does on the host
             if (!host_asm)
@@ -500,7 +507,7 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
                                    use_arg ? 1 : 0, targ, theta_dev, c->d_tmm, c->d_edge_ts, c->n_items, c->d_items, c->d_wins,
                                    c->n_items_s, c->d_items_s, c->d_wins_s);
         } else {
-            launch_theta_image(c, h, w, identity, use_arg, targ, theta_dev, true);
+            launch_theta_image(c, h, w, identity, use_arg_big, targ_big, theta_dev, true);
             if (nwin_threads > 0 && !c->itembase_valid)
                 hipLaunchKernelGGL(k_windows, dim3((nwin_threads + NT - 1) / NT), dim3(NT), 0, c->stream, g, c->d_tmm, c->d_edge_ts,
                                    c->n_items, c->d_items, c->d_wins, c->n_items_s, c->d_items_s, c->d_wins_s);
@@ -1949,7 +1956,7 @@ static int ensure_theta_image(eincm_ctx* c) {
     if (rc) return rc;
     memcpy(c->h_theta, c->last_theta11.data(), c->last_theta11.size() * sizeof(double));
     c->g.wmask = ~0ull;                              // every window's image, whatever the last evaluation masked
-    ThetaArg targ{};
+    static const ThetaArgBig targ{};
     launch_theta_image(c, 1, 1, false, false, targ, c->h_theta, false);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -178,6 +178,8 @@ struct EvalParams {
 
 constexpr int THETA_ARG_MAX = 128;    // doubles of theta that ride in the kernel arguments instead of an H2D copy
 struct ThetaArg { double v[THETA_ARG_MAX]; };
+constexpr int THETA_ARG_BIG = 512;    // k_theta alone takes up to a 16x16 theta of one window (4 KiB) in its arguments: no read of pinned host memory
+struct ThetaArgBig { double v[THETA_ARG_BIG]; };
 
 struct OutScal {                  // per-window result block written by k_final
     double value, mean_rel_corr, mean_rel_contrast, mean_rel_div, tv, tv_scale, nonfinite, _pad;
@@ -369,7 +371,7 @@ __device__ __forceinline__ void stage_resample_weights(ResampleLds& L, const Res
 // grid (ntiles, B).  identity: theta already is (H,W,2).  Not launched for 2-DoF theta unless somebody needs the Theta image
 // (k_theta_const fills the velocity bounds then).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity, int use_arg, ThetaArg targ,
+__global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity, int use_arg, ThetaArgBig targ,
         const double* __restrict__ theta,      // (B,h,w,2)
         const double* __restrict__ AH,         // (H,h)
         const double* __restrict__ AW,         // (W,w)
