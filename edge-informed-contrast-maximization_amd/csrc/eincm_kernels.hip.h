@@ -178,7 +178,7 @@ struct EvalParams {
 
 constexpr int THETA_ARG_MAX = 128;    // doubles of theta that ride in the kernel arguments instead of an H2D copy
 struct ThetaArg { double v[THETA_ARG_MAX]; };
-constexpr int THETA_ARG_BIG = 512;    // k_theta alone takes up to a 16x16 theta of one window (4 KiB) in its arguments: no read of pinned host memory
+constexpr int THETA_ARG_BIG = 4096;   // k_theta alone takes up to 32 KiB of theta (16x16 grids of 8 windows) in its arguments: no read of pinned host memory
 struct ThetaArgBig { double v[THETA_ARG_BIG]; };
 
 struct OutScal {                  // per-window result block written by k_final

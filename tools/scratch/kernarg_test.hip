@@ -12,4 +12,4 @@ template <int N> void run() {
     printf("N=%d (%d bytes): launch %s, sync %s, sum %g\n", N, N * 8, hipGetErrorString(e), hipGetErrorString(e2), h);
     hipFree(d);
 }
-int main() { run<128>(); run<500>(); run<512>(); run<520>(); run<600>(); run<1024>(); return 0; }
+int main() { run<1024>(); run<2048>(); run<4096>(); run<8000>(); return 0; }
