@@ -475,6 +475,7 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
         if (const_theta) need_theta_image = true;    // (no host copy of theta for ensure_theta_image to rebuild the image from)
     } else if (use_arg) {
         memcpy(targ.v, theta_host, (size_t)g.B * nth * sizeof(double));     // theta rides in the kernel arguments
+        if (!use_arg_big) { memcpy(c->h_theta, theta_host, (size_t)g.B * nth * sizeof(double)); theta_dev = c->h_theta; }   // (k_theta reads memory then)
     } else if (use_arg_big) {
         theta_dev = c->h_theta;                      // (not read: k_theta has theta in its arguments)
     } else if ((size_t)g.B * nth <= ZERO_COPY_MAX) {

@@ -20,6 +20,7 @@ SWITCHES = [
     ({'EINCM_COMPOSE': '1'}, 'fused statistics + composing gather (DESIGN 4.3)'),
     ({'EINCM_SPLAT_MERGE': '1'}, 'run-merged forward accumulation (DESIGN 4.4)'),
     ({'EINCM_NO_HOST_ASM': '1'}, 'scalar assembly on the device (k_final)'),
+    ({'EINCM_NO_BIG_THETA_ARG': '1'}, 'k_theta reads theta from the pinned staging buffer instead of its kernel arguments'),
     ({'EINCM_NO_PROJ_IN_GATHER': '1'}, 'dL/dTheta image + k_project instead of the in-gather projection'),
     ({'EINCM_NO_SEGSORT': '1', 'EINCM_NO_SPREAD': '1'}, 'both event copies in plain time order'),
     ({'EINCM_SEG': '4096', 'EINCM_SEG_SPLAT': '2048', 'EINCM_SEG_2DOF': '8192'}, 'other segment lengths'),
