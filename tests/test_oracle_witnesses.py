@@ -35,6 +35,24 @@ def test_bilinear_antialiased_downsampling_matches_torch(n_in, n_out):
     assert np.allclose(A.sum(axis=1), 1.0, atol=1e-15)
 
 
+@pytest.mark.parametrize('method,pil_name', [('cubic', 'BICUBIC'), ('lanczos3', 'LANCZOS'), ('bilinear', 'BILINEAR')])
+def test_cubic_and_lanczos3_match_pillow(method, pil_name):
+    """jax.image.scale_and_translate's 'cubic' (Keys, a = -0.5) and 'lanczos3' kernels with half-pixel centres, the support stretched
+    when down-sampling and the weights renormalised at the borders are Pillow's BICUBIC / LANCZOS resize (which jax.image documents as
+    its model).  Pillow is importable here: the operator matrices agree to its float32 precision, for the up-sampling of theta
+    (theta_utils.py:25-35) and for the lanczos3 down-sampling of the pyramid priors (solver.py:350-377).  lanczos5 has no witness."""
+    Image = pytest.importorskip('PIL.Image')
+    flt = getattr(Image, pil_name)
+    for n_in, n_out in ((16, 260), (16, 346), (4, 37), (346, 16), (260, 16), (16, 8), (8, 4), (33, 7), (2, 5), (1, 9)):
+        A = O.resample_matrix(n_in, n_out, n_out / n_in, method)               # (n_out, n_in)
+        P = np.zeros((n_out, n_in))
+        for k in range(n_in):
+            e = np.zeros((1, n_in), dtype=np.float32)
+            e[0, k] = 1.0
+            P[:, k] = np.asarray(Image.fromarray(e, mode='F').resize((n_out, 1), resample=flt), dtype=np.float64)[0]
+        assert np.abs(A - P).max() <= 2e-7, (method, n_in, n_out, np.abs(A - P).max())
+
+
 def test_adjoint_is_the_transpose():
     rng = np.random.default_rng(0)
     theta = rng.normal(size=(4, 6, 2)); G = rng.normal(size=(37, 53, 2))
