@@ -89,6 +89,20 @@ def test_gaussian_kernel_and_blur_properties():
         ES.smoothen_edges(np.zeros((3, 20)))
 
 
+def test_gaussian_blur_matches_scipy_ndimage():
+    """The restated cv.GaussianBlur (normalised exp taps on round(8 sigma + 1) | 1 samples, separable, BORDER_REFLECT_101) is
+    scipy.ndimage.gaussian_filter with mode='mirror' and the same radius.  OpenCV itself is absent, so which kernel SIZE OpenCV picks
+    for a float64 image stays the restatement's claim (cv::getGaussianKernel / createGaussianKernels); the filter given that size is
+    witnessed here."""
+    from scipy import ndimage
+    rng = np.random.default_rng(0)
+    img = (rng.random((60, 80)) > 0.9).astype(np.float64)
+    for sigma in (0.8, 1.0, 2.0, 3.3):
+        r = (len(ES.gaussian_kernel_cv(sigma)) - 1) // 2
+        np.testing.assert_allclose(ES.smoothen_edges(img, k_size=sigma, sigma=7), ndimage.gaussian_filter(img, sigma=sigma, mode='mirror', radius=r),
+                                   rtol=0, atol=1e-15)
+
+
 def test_tiled_objectives():
     rng = np.random.default_rng(3)
     a, b = rng.random((70, 90)), rng.random((70, 90))
