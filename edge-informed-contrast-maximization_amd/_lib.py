@@ -77,6 +77,7 @@ SIGNATURES = [
     ('eincm_get_count_images', C.c_int, [_P, C.POINTER(C.c_uint32)]),
     ('eincm_loss_grad_device', C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_double, C.POINTER(C.c_double), C.c_void_p,
                                         C.POINTER(Aux)]),
+    ('eincm_set_timing_period', C.c_int, [_P, C.c_int]),
     ('eincm_get_warped_events', C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ('eincm_multi_ref_weights', C.c_int, [C.c_int, _D]),
     ('eincm_resample_matrix', C.c_int, [C.c_int, C.c_int, C.c_int, _D]),

@@ -164,6 +164,7 @@ struct eincm_ctx {
     int n_pieces = 0;              // pieces of the evaluation in flight (0: the gradient came with the results / in one copy)
     size_t piece_len = 0;
     int attach_stage = -1;         // EINCM_CF_TIMING: the single-kernel stage whose launch takes its events along (StageTimer)
+    int time_period = 1; int64_t time_counter = 0; bool timed_now = true;   // EINCM_CF_TIMING_DOMINANT: events on every time_period-th evaluation only (eincm_set_timing_period)
     bool time_splat = true, time_gather = true;   // EINCM_CF_TIMING_DOMINANT: which event kernels carry start / stop events (eincm_set_timed_kernels)
     bool have_events = false;
     eincm_timings last_t{};
@@ -320,10 +321,14 @@ struct StageTimer {
 // EINCM_CF_TIMING_DOMINANT: the two event kernels are launched with their own start / stop events (hipExtLaunchKernelGGL: the
 // dispatch's completion signal carries the timestamps).  Marker events around them (hipEventRecord) cost 25 us per evaluation in
 // barrier packets and lost launch overlap; attached events cost ~6 us per timed kernel.
+static inline bool timing_on(const eincm_ctx* c) {
+    return (c->cflags & EINCM_CF_TIMING) != 0 || ((c->cflags & EINCM_CF_TIMING_DOMINANT) != 0 && c->timed_now);
+}
+
 template <typename K, typename... Args>
 void launch_timed(eincm_ctx* c, int stage, K kernel, dim3 grid, dim3 block, size_t lds, Args... args) {
     const bool attach = (c->cflags & EINCM_CF_TIMING) ? c->attach_stage == stage
-                      : (c->cflags & EINCM_CF_TIMING_DOMINANT) ? (stage == EINCM_STAGE_SPLAT ? c->time_splat : stage == EINCM_STAGE_GATHER && c->time_gather)
+                      : ((c->cflags & EINCM_CF_TIMING_DOMINANT) && c->timed_now) ? (stage == EINCM_STAGE_SPLAT ? c->time_splat : stage == EINCM_STAGE_GATHER && c->time_gather)
                       : false;
     if (attach) {
         hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, c->stream, c->ev[c->ring_cur][stage][0], c->ev[c->ring_cur][stage][1], 0,
@@ -574,7 +579,7 @@ int drain_event_ring(eincm_ctx* c, int keep) {          // read the oldest finis
 }
 // The evaluation in flight has finished (stream waited for): its events join the ring; read at once unless the mode defers it.
 int collect_timings(eincm_ctx* c) {
-    if (!(c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT))) return EINCM_OK;
+    if (!timing_on(c)) return EINCM_OK;
     ++c->ring_n;
     return (c->ring_size == 1) ? drain_event_ring(c, 0) : EINCM_OK;
 }
@@ -616,7 +621,8 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         if (rc) return rc;
     }
     if (c->acc_dirty) { const int rcd = clear_accumulators(c); if (rcd) return rcd; }
-    const bool timing = (c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)) != 0;
+    if (c->cflags & EINCM_CF_TIMING_DOMINANT) c->timed_now = (c->time_counter++ % c->time_period) == 0;
+    const bool timing = timing_on(c);
     if (timing) {
         if (c->ring_n == c->ring_size) { const int rcr = drain_event_ring(c, c->ring_size - 1); if (rcr) return rcr; }   // ring full: read the oldest
         c->ring_cur = (c->ring_lo + c->ring_n) % c->ring_size;
@@ -741,7 +747,7 @@ int eval_end_launch(eincm_ctx* c) {
     const int h = c->pend.h, w = c->pend.w;
     const bool identity = c->pend.identity, want_grad = c->pend.want_grad, full_aux = c->pend.full_aux, div_grad = c->pend.div_grad;
     const size_t nth = (size_t)h * w * 2;
-    const bool timing = (c->cflags & (EINCM_CF_TIMING | EINCM_CF_TIMING_DOMINANT)) != 0;
+    const bool timing = timing_on(c);
     const bool host_asm = c->pend.host_asm;
     // The image pass of a gradient evaluation.  Default: k_stats_stream -> k_imgrad -> gather.  EINCM_COMPOSE=1 selects the fused
     // form built in round 3: k_imstat (statistics + the stats-independent part of dL/dIWE in one kernel, the per-image scalars in its
@@ -2176,6 +2182,15 @@ int eincm_set_timed_kernels(eincm_ctx* c, int splat, int gather) {
     if (!(c->cflags & EINCM_CF_TIMING_DOMINANT)) return fail(c, EINCM_ERR_STATE, "context was created without EINCM_CF_TIMING_DOMINANT");
     if (c->pend.active) return fail(c, EINCM_ERR_STATE, "an evaluation is in flight");
     c->time_splat = splat != 0; c->time_gather = gather != 0;
+    return EINCM_OK;
+}
+
+int eincm_set_timing_period(eincm_ctx* c, int period) {
+    if (!c) return EINCM_ERR_ARG;
+    if (!(c->cflags & EINCM_CF_TIMING_DOMINANT)) return fail(c, EINCM_ERR_STATE, "context was created without EINCM_CF_TIMING_DOMINANT");
+    if (c->pend.active) return fail(c, EINCM_ERR_STATE, "an evaluation is in flight");
+    if (period < 1) return fail(c, EINCM_ERR_ARG, "period %d", period);
+    c->time_period = period; c->time_counter = 0;
     return EINCM_OK;
 }
 

@@ -432,6 +432,10 @@ class Engine:
         """timing='dominant' contexts: which event kernels carry HIP timing events from the next evaluation on."""
         self._check(self._lib.eincm_set_timed_kernels(self._ctx, 1 if splat else 0, 1 if gather else 0))
 
+    def set_timing_period(self, period):
+        """timing='dominant' contexts: timing events on every ``period``-th evaluation only."""
+        self._check(self._lib.eincm_set_timing_period(self._ctx, int(period)))
+
     def timings(self):
         t = L.Timings()
         self._check(self._lib.eincm_get_timings(self._ctx, C.byref(t)))

@@ -25,7 +25,7 @@ extern "C" {
 
 #define EINCM_ABI_VERSION 5   /* 2: eincm_iwe_device_ptr hands out the u64 fixed-point accumulator of the IWE stack; 3: eincm_set_timed_kernels, eincm_set_windows_ptrs;
                                 * 4: eincm_loss_grad_masked, eincm_set_device_results / eincm_finish_launch / eincm_grad_device_ptr / eincm_finish_collect, eincm_get_host_profile;
-                               * 5: eincm_get_warped_events, eincm_loss_grad_device, eincm_loss_grad_masked_async */
+                               * 5: eincm_get_warped_events, eincm_loss_grad_device, eincm_loss_grad_masked_async, eincm_set_timing_period */
 
 #define EINCM_OK               0
 #define EINCM_ERR_ARG         -1   /* bad argument (shape, null pointer, out-of-range event coordinate) */
@@ -220,6 +220,9 @@ int eincm_get_timings(eincm_ctx* ctx, eincm_timings* t);
 /* EINCM_CF_TIMING_DOMINANT contexts: which of the two event kernels carry timing events from the next evaluation on (both by
  * default).  A timed launch costs ~6 us of an evaluation; a throughput measurement times only the kernel it reports. */
 int eincm_set_timed_kernels(eincm_ctx* ctx, int splat, int gather);
+/* ... and on every `period`-th evaluation only (1 = every evaluation): a timed launch costs ~6 us of a 240 us step; eincm_get_timings_total
+ * reports how many evaluations its sums cover.  The counter restarts with the call. */
+int eincm_set_timing_period(eincm_ctx* ctx, int period);
 
 /* Host-side wall time (microseconds, summed since the last reset) the calling thread spent in the phases of the evaluations of
  * this context, and their number: [EINCM_HP_BEGIN] argument checks, theta staging and the launches of the forward half,
