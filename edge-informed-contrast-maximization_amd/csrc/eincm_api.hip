@@ -649,8 +649,10 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         // time span of a typical splat segment: seg_s events out of the average tile population
         const double per_tile = (double)std::max<int64_t>(c->n_events, 1) / ((double)g.B * g.ntiles);
         const double tspan = std::min(1.0, (double)c->seg_s_used / std::max(per_tile, 1.0));
+        // LDS holds pitch x height words per window, the pitch being the width rounded up to the 32 banks (win_pitch)
+        auto lds_words = [](double side_px) { const double sd = std::ceil(side_px); return std::ceil(sd / 32.0) * 32.0 * sd; };
         const double side = TS + 4 + vmax * tspan;
-        const double need = side * side;
+        const double need = lds_words(side);
         static const int caps[] = {2304, 3072, 4608, 6912};      // 6912 keeps k_gather's LDS (window + accumulators + Theta tile) under 64 KiB
         int cap = caps[3];
         for (int k = 0; k < 4; ++k) if (need <= caps[k]) { cap = caps[k]; break; }
@@ -664,7 +666,7 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         const double tspan_a = std::min(1.0, (double)c->seg_used / std::max(per_tile, 1.0));
         const double side_a = TS + 4 + vmax * tspan_a;
         int cap_a = caps[3];
-        for (int k = 0; k < 4; ++k) if (side_a * side_a <= caps[k]) { cap_a = caps[k]; break; }
+        for (int k = 0; k < 4; ++k) if (side_a * side_a <= caps[k]) { cap_a = caps[k]; break; }          // (the theta-grid gather's windows: pitch = width)
         cap_a = std::max(cap_a, cap);
         c->g.wincap_a = cap_a;
         c->g.winmaxw_a = std::max(40, (int)std::lround(std::sqrt((double)cap_a * 1.4)));
@@ -672,7 +674,7 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         const double tspan_2 = std::min(1.0, (double)c->seg_2_used / std::max(per_tile, 1.0));
         const double side_2 = TS + 4 + vmax * tspan_2;
         int cap_2 = caps[3];
-        for (int k = 0; k < 4; ++k) if (side_2 * side_2 <= caps[k]) { cap_2 = caps[k]; break; }
+        for (int k = 0; k < 4; ++k) if (lds_words(side_2) <= caps[k]) { cap_2 = caps[k]; break; }
         c->wincap_2 = cap_2;
     }
     // 2-DoF theta with nothing but the contrast and correlation terms (every level above 0 of the reference's pyramid at its first

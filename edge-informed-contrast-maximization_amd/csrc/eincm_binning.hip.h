@@ -138,8 +138,8 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_scatter(Geom g, const BinBlock* 
 }
 
 // Re-deal the events inside every block of 256 consecutive events of a tile (the 256 events the threads of an event-kernel workgroup
-// take in one trip): sorted by source pixel, then dealt round-robin to the four 64-event groups, so that the events a wavefront
-// handles together come from different source pixels.  Events of one source pixel at nearby times land on one destination pixel,
+// take in one trip): sorted by source pixel (column-major), then dealt round-robin to the eight 32-event half-waves, so that the events a
+// half-wave handles together come from different source COLUMNS (hence different pixels).  Events of one source pixel at nearby times land on one destination pixel,
 // and LDS atomics are slower on shared destinations (profiles/r02/splat_bound_experiment.txt): k_splat gains 4-6 %.  The
 // permutation is a function of the block's content alone (keys are unique: pixel, then position), so re-staging reproduces it;
 // segments are multiples of 256 events from the tile's start, so no event changes segment.  A trailing partial block keeps its order.
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void k_spread(Geom g, const int32_t* __restric
         const uint32_t xy = ev_xy[base + b0 + t];
         const double tm = ev_t[base + b0 + t];
         // pixel inside the 32x32 tile (10 bits) above the position in the block (8 bits)
-        const uint32_t key = (((xy >> 11) & (31u << 5)) | (xy & 31u)) << 8 | (uint32_t)t;      // (a Morton key of the pixel measured the same)
+        // pixel inside the 32x32 tile, COLUMN-major (10 bits: x, then y), above the position in the block (8 bits)
+        const uint32_t key = (((xy & 31u) << 5) | ((xy >> 16) & 31u)) << 8 | (uint32_t)t;
         __syncthreads();                                  // the previous block's keys are no longer read
         keys[t] = key;
         __syncthreads();
@@ -167,7 +168,10 @@ __global__ __launch_bounds__(256) void k_spread(Geom g, const int32_t* __restric
             const uint4 q = k4[k];
             rank += (q.x < key ? 1 : 0) + (q.y < key ? 1 : 0) + (q.z < key ? 1 : 0) + (q.w < key ? 1 : 0);
         }
-        const int pos = (rank & 3) * 64 + (rank >> 2);
+        // rank r of the column-major order goes to half-wave r mod 8, slot r / 8: the 32 lanes of a half-wave get ascending columns,
+        // all different unless a column holds more than 8 of the block's events (win_pitch in eincm_kernels.hip.h: bank = column)
+        const int hw = rank & 7;
+        const int pos = (hw >> 1) * 64 + (hw & 1) * 32 + (rank >> 3);
         ev_xy[base + b0 + pos] = xy;                      // every thread has read its event: the block-local permutation is safe in place
         ev_t[base + b0 + pos] = tm;
     }

@@ -234,7 +234,17 @@ struct Window { int ox, oy, ww, wh; };
 // Destination bounding box of an item at reference time tau: source tile shifted by -v*dt for
 // v in the tile's velocity bounds and dt in the item's time range, +1 for the 3x3 taps, +1 for rounding.
 // Clamped to WIN_CAP floats; taps that fall outside take the (rare) direct-to-HBM path, so ANY box is correct.
-__device__ __forceinline__ Window item_window(const Geom& g, const Item& it, const double* __restrict__ mm4, double tau, int wincap, int winmaxw) {
+// Row pitch of a window in LDS: the width rounded up to the 32 banks.  The bank of a tap is then its window COLUMN (mod 32) whatever
+// its row, and staging deals the events so that the 32 lanes of a half-wave come from 32 different source columns (k_spread): their
+// nine taps fall on 32 different banks.  tools/lds_atomic_bench2.hip: 11.4 ds_add_u32 lane-ops per clock and CU that way, 9.8 with a
+// +-1 column jitter on 30 % of the lanes, 7.2 with random columns (what a pitch equal to the width gives).
+__device__ __forceinline__ int win_pitch(int ww) { return (ww + 31) & ~31; }
+
+// aligned: the window is stored at the bank-aligned pitch (the splat's copy of the events: k_splat and the 2-DoF gather); the theta-grid
+// gather walks the pixel-sorted copy, whose half-waves hold neighbouring pixels of two or three rows: there a pitch of 64 lets the rows
+// alias onto the same banks (146 -> 150 us), so it keeps pitch = width.
+__device__ __forceinline__ Window item_window(const Geom& g, const Item& it, const double* __restrict__ mm4, double tau, int wincap, int winmaxw,
+                                              bool aligned = true) {
     const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
     const int x1 = min(x0 + TS, g.W) - 1, y1 = min(y0 + TS, g.H) - 1;
@@ -253,9 +263,9 @@ __device__ __forceinline__ Window item_window(const Geom& g, const Item& it, con
     int bx0 = x0 + (int)lo[0] - 2, bx1 = x1 + (int)hi[0] + 2;
     int by0 = y0 + (int)lo[1] - 2, by1 = y1 + (int)hi[1] + 2;
     int ww = bx1 - bx0 + 1, wh = by1 - by0 + 1;
-    if (ww * wh > wincap || ww > winmaxw) {
+    if ((aligned ? win_pitch(ww) : ww) * wh > wincap || ww > winmaxw) {          // (LDS holds pitch x wh words)
         const int nww = min(ww, winmaxw);
-        const int nwh = min(wh, wincap / nww);
+        const int nwh = min(wh, wincap / (aligned ? win_pitch(nww) : nww));
         bx0 = (bx0 + bx1) / 2 - nww / 2;
         by0 = (by0 + by1) / 2 - nwh / 2;
         ww = nww; wh = nwh;
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
         const int item = (first ? a0 : b0) + kk / g.R, r = kk % g.R;
         const Item it = (first ? items_a : items_b)[item];
         (first ? wins_a : wins_b)[(size_t)item * g.R + r] = item_window(g, it, mm4, edge_ts[it.win * g.R + r], first ? g.wincap_a : g.wincap,
-                                                                          first ? g.winmaxw_a : g.winmaxw);
+                                                                          first ? g.winmaxw_a : g.winmaxw, !first);
     }
 }
 
@@ -518,7 +528,7 @@ __device__ __forceinline__ void windows_of(const Geom& g, int idx, int n_a, cons
         const double* mm = tmm + ((size_t)it.win * g.ntiles + it.tile) * 4;
         mm4[0] = mm[0]; mm4[1] = mm[1]; mm4[2] = mm[2]; mm4[3] = mm[3];
     }
-    (first ? wins_a : wins_b)[k] = item_window(g, it, mm4, edge_ts[it.win * g.R + r], first ? g.wincap_a : g.wincap, first ? g.winmaxw_a : g.winmaxw);
+    (first ? wins_a : wins_b)[k] = item_window(g, it, mm4, edge_ts[it.win * g.R + r], first ? g.wincap_a : g.wincap, first ? g.winmaxw_a : g.winmaxw, !first);
 }
 
 // 2-DoF theta (1,1,2): Theta is one constant per window, so the velocity bounds of every tile are that constant; no image is
@@ -658,10 +668,12 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         wn = wins[(size_t)item * g.R + r];
     }
     const int nwin = wn.ww * wn.wh;
+    const int wp = MERGE ? wn.ww : win_pitch(wn.ww), nlds = wp * wn.wh;     // LDS row pitch and words (win_pitch; the MERGE experiment walks the
+                                                                            // gather's list, whose window table is sized for pitch = width)
     const bool multi = MULTI != 0 && it.count > chunk;       // MULTI == 0: the commit logic in the loop folds away
     {   // clear the window(s), 16 B per lane
         uint4* z = reinterpret_cast<uint4*>(ldsu);
-        const int nq = (nwin + 3) >> 2;
+        const int nq = (nlds + 3) >> 2;
         for (int i = threadIdx.x; i < nq; i += NTH) z[i] = make_uint4(0u, 0u, 0u, 0u);
         if (multi) { uint4* zf = reinterpret_cast<uint4*>(ldsf); for (int i = threadIdx.x; i < nq; i += NTH) zf[i] = make_uint4(0u, 0u, 0u, 0u); }
     }
@@ -693,9 +705,9 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         taps3x2(fx, fy, scy, km, k0, kp);
         const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;        // window coords of the top-left tap
         if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
-            uint32_t* p = ldsu + __mul24(ly, wn.ww) + lx;
+            uint32_t* p = ldsu + __mul24(ly, wp) + lx;
             // 3x3 products ky[dy]*kx[dx] + 0.5 (scalar FMAs: packed ones are slower on gfx950), then truncating converts
-            uint32_t* p1 = p + wn.ww; uint32_t* p2 = p1 + wn.ww;
+            uint32_t* p1 = p + wp; uint32_t* p2 = p1 + wp;
             atomicAdd(p, fix_u32(km.y, km.x)); atomicAdd(p + 1, fix_u32(km.y, k0.x)); atomicAdd(p + 2, fix_u32(km.y, kp.x));
             atomicAdd(p1, fix_u32(k0.y, km.x)); atomicAdd(p1 + 1, fix_u32(k0.y, k0.x)); atomicAdd(p1 + 2, fix_u32(k0.y, kp.x));
             atomicAdd(p2, fix_u32(kp.y, km.x)); atomicAdd(p2 + 1, fix_u32(kp.y, k0.x)); atomicAdd(p2 + 2, fix_u32(kp.y, kp.x));
@@ -708,7 +720,7 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
                 for (int dx = 0; dx < 3; ++dx) {
                     const int cx = lxs + dx, cy = lys + dy;
                     if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
-                        atomicAdd(ldsu + cy * wn.ww + cx, fix_u32(ky[dy], kx[dx]));
+                        atomicAdd(ldsu + cy * wp + cx, fix_u32(ky[dy], kx[dx]));
                     } else {
                         const int gx = wrap_drop(sx - 1 + dx, g.W), gy = wrap_drop(sy - 1 + dy, g.H);
                         // straight to HBM in the accumulator's own scale (ky carries 2^fshift; a tap * 2^30 fits 32 bits)
@@ -726,7 +738,7 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         if (e < n) splat_ev(cur);
         if (multi && ((j + 1) % ipc == 0 || j + 1 == iters)) {     // chunk boundary (uniform): commit u32 -> f32 window
             __syncthreads();
-            for (int i = tid; i < nwin; i += NTH) {
+            for (int i = tid; i < nlds; i += NTH) {
                 const uint32_t u = ldsu[i];
                 if (u != 0u) { ldsf[i] += (float)u * FIX_INV; ldsu[i] = 0u; }
             }
@@ -738,7 +750,7 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0, m8 = 0;
         auto flush9 = [&]() {
             if (cur_off < 0) return;
-            uint32_t* p = ldsu + cur_off; uint32_t* p1 = p + wn.ww; uint32_t* p2 = p1 + wn.ww;
+            uint32_t* p = ldsu + cur_off; uint32_t* p1 = p + wp; uint32_t* p2 = p1 + wp;
             atomicAdd(p, m0); atomicAdd(p + 1, m1); atomicAdd(p + 2, m2);
             atomicAdd(p1, m3); atomicAdd(p1 + 1, m4); atomicAdd(p1 + 2, m5);
             atomicAdd(p2, m6); atomicAdd(p2 + 1, m7); atomicAdd(p2 + 2, m8);
@@ -754,7 +766,7 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
             if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
                 f2v km, k0, kp;
                 taps3x2(fx, fy, scy, km, k0, kp);
-                const int off = __mul24(ly, wn.ww) + lx;
+                const int off = __mul24(ly, wp) + lx;
                 const uint32_t t0 = fix_u32(km.y, km.x), t1 = fix_u32(km.y, k0.x), t2 = fix_u32(km.y, kp.x);
                 const uint32_t t3 = fix_u32(k0.y, km.x), t4 = fix_u32(k0.y, k0.x), t5 = fix_u32(k0.y, kp.x);
                 const uint32_t t6 = fix_u32(kp.y, km.x), t7 = fix_u32(kp.y, k0.x), t8 = fix_u32(kp.y, kp.x);
@@ -810,7 +822,7 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         // the usual case, the window lies inside the image: no index rule per pixel
         unsigned long long* __restrict__ dst = img + (size_t)wn.oy * g.W + wn.ox;
         for (WinWalkT<NTH> w(threadIdx.x, wn.ww); w.i < nwin; w.next()) {
-            const unsigned long long v = to_acc(w.i);
+            const unsigned long long v = to_acc(w.row * wp + w.col);
             if (v != 0ull) atomicAdd(dst + w.row * g.W + w.col, v);
         }
         return;
@@ -819,7 +831,7 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         const int gy = wrap_drop(wn.oy + row, g.H);
         if (gy < 0) continue;
         for (int col = lane; col < wn.ww; col += 64) {
-            const unsigned long long v = to_acc(row * wn.ww + col);
+            const unsigned long long v = to_acc(row * wp + col);
             if (v != 0ull) {
                 const int gx = wrap_drop(wn.ox + col, g.W);
                 if (gx >= 0) atomicAdd(img + (size_t)gy * g.W + gx, v);
@@ -1518,7 +1530,7 @@ __global__ __launch_bounds__(NT) void k_divgrad(Geom g, const float* __restrict_
 // dL/dw of one event at one reference time: the event is warped like in the forward pass, its 3x3 neighbourhood of G = dL/dIWE is
 // read from the LDS window `lds` (bounding box wn; taps outside it straight from the image Gi with the JAX wrap/drop rule).
 template <typename GAt>      // GAt: float operator()(size_t pixel) - dL/dIWE of this (window, reference time) at a pixel of the image
-__device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, const float* lds, const GAt& Gi,
+__device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, int wp /* LDS row pitch of the window */, const float* lds, const GAt& Gi,
                                            int x, int y, double2 v, double dt, float& gwx, float& gwy) {
     int irx, iry; float fx, fy;
     warp_axis(x, v.x, dt, irx, fx);
@@ -1535,7 +1547,7 @@ __device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, cons
     const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;
     if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
         // byte offsets with the row stride pre-scaled (a scalar): one v_mul_i32_i24 + one v_lshl_add_u32, then one add per further row
-        const int ww4 = wn.ww * 4;
+        const int ww4 = wp * 4;
         const char* pb = reinterpret_cast<const char*>(lds) + (__mul24(ly, ww4) + (lx << 2));
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
@@ -1552,7 +1564,7 @@ __device__ __forceinline__ void event_dLdw(const Geom& g, const Window& wn, cons
                 const int cx = lxs + dx, cy = lys + dy;
                 float val = 0.0f;
                 if (cx >= 0 && cy >= 0 && cx < wn.ww && cy < wn.wh) {
-                    val = lds[cy * wn.ww + cx];
+                    val = lds[cy * wp + cx];
                 } else {
                     const int gx = wrap_drop(sx - 1 + dx, g.W), gy = wrap_drop(sy - 1 + dy, g.H);
                     if (gx >= 0 && gy >= 0) val = Gi((size_t)gy * g.W + gx);
@@ -1706,6 +1718,7 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
     } else {
         wn = wins[(size_t)item * g.R + r];
     }
+    const int wp = (theta_mode == THETA_CONST) ? win_pitch(wn.ww) : wn.ww;      // LDS row pitch of the G window (see item_window)
     const size_t img = ((size_t)it.win * g.R + r) * g.H * g.W;
     const float* __restrict__ Gi = G + img;
     const float* __restrict__ Ei = edges + img;
@@ -1733,13 +1746,13 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
     };
     if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {      // the usual case: window inside the image
         const size_t o0 = (size_t)wn.oy * g.W + wn.ox;
-        for (WinWalkT<NTH> w(threadIdx.x, wn.ww); w.i < wn.ww * wn.wh; w.next()) lds[w.i] = G_at(o0 + w.row * g.W + w.col);
+        for (WinWalkT<NTH> w(threadIdx.x, wn.ww); w.i < wn.ww * wn.wh; w.next()) lds[w.row * wp + w.col] = G_at(o0 + w.row * g.W + w.col);
     } else {
         for (int row = wv; row < wn.wh; row += NTH / 64) {
             const int gy = wrap_drop(wn.oy + row, g.H);
             for (int col = lane; col < wn.ww; col += 64) {
                 const int gx = wrap_drop(wn.ox + col, g.W);
-                lds[row * wn.ww + col] = (gx >= 0 && gy >= 0) ? G_at((size_t)gy * g.W + gx) : 0.0f;
+                lds[row * wp + col] = (gx >= 0 && gy >= 0) ? G_at((size_t)gy * g.W + gx) : 0.0f;
             }
         }
     }
@@ -1792,7 +1805,7 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
 #endif
         }
         float gwx, gwy;
-        event_dLdw(g, wn, lds, G_far, x, y, vcur, dt, gwx, gwy);
+        event_dLdw(g, wn, wp, lds, G_far, x, y, vcur, dt, gwx, gwy);
         if (direct11) {          // theta (1,1,2): Theta is constant, dL/dtheta = sum over all events; no per-pixel image needed.
             // fp32 over the thread's own <= 64 terms (their rounding errors are independent across 10^6 threads and average out:
             // measured 1e-9 relative on the gradient), fp64 from there on

@@ -244,7 +244,7 @@ int eincm_get_timings_total(eincm_ctx* ctx, eincm_timings* sum, int64_t* n_evals
  *   theta_dev      (n_windows, h, w, 2) float64 in the memory of the context's device, complete when the call is made (the engine runs
  *                  on its own stream: synchronise the stream that produced theta first)
  *   theta_abs_max  an upper bound of |theta| (px per unit time) if the caller has one, < 0 otherwise: it only selects the capacity of
- *                  the LDS windows (any value is correct; a bound far too small or unknown costs speed)
+ *                  the LDS windows (any value is correct - results agree to a fixed-point quantum; a bound far too small or unknown costs speed)
  *   value          (n_windows) on the HOST; aux optional, on the host
  *   grad_dev       (n_windows, h, w, 2) float64 on the device, or NULL for a forward-only evaluation; complete on return
  * EINCM_ERR_NONFINITE reports a non-finite value or theta (the device gradient is not scanned). */

@@ -39,11 +39,13 @@ def test_device_resident_theta_and_gradient(built_lib):
             assert rel(v_d, v_h) <= 1e-10 and rel(g_dn, g_h) <= 1e-9, (hw, rel(v_d, v_h), rel(g_dn, g_h))
             for k in ('mean_rel_corr', 'mean_rel_contrast', 'theta_total_variation'):
                 assert aux_d[0][k] == pytest.approx(aux_h[0][k], rel=1e-10, abs=1e-300), (hw, k)
-            # a bound on |theta| only selects LDS window capacities: the results do not depend on it (integer accumulation)
+            # a bound on |theta| only selects LDS window capacities: as long as the windows hold every tap the results are bit for bit the same
             v_b, g_b, _ = eng.loss_grad_device(t, p, theta_abs_max=float(np.abs(th).max()))
             assert np.array_equal(v_b, v_d) and torch.equal(g_b, g_d), hw
-            v_s, g_s, _ = eng.loss_grad_device(t, p, theta_abs_max=0.0)          # a bound far too small: slow path, same sums
-            assert rel(v_s, v_d) <= 1e-12 and rel(g_s.cpu().numpy(), g_dn) <= 1e-9, hw
+            # a bound far too small: taps that miss the window go straight to HBM, rounded at the accumulator's scale (2^-30) instead of
+            # the segment's (2^-21): the same image to a fixed-point quantum
+            v_s, g_s, _ = eng.loss_grad_device(t, p, theta_abs_max=0.0)
+            assert rel(v_s, v_d) <= 1e-7 and rel(g_s.cpu().numpy(), g_dn) <= 1e-6, hw
             for b in range(B):                                                   # and against the oracle
                 v_o, g_o, _ = O.loss_and_grad(th[b], *args[b], 20.0, 35.0, gamma, 0.0, lvl, 5, (H, W))
                 assert abs(v_d[b] - v_o) <= TOL * abs(v_o) and rel(g_dn[b], g_o) <= TOL, (hw, b)

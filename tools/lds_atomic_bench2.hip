@@ -45,7 +45,7 @@ int main() {
     int* d; unsigned* o;
     CHK(hipMalloc(&d, n * 4)); CHK(hipMalloc(&o, nblk * 4));
     std::vector<int> h(n);
-    struct Case { const char* name; int ww, wh, lds_words, sites; int interleave; int copies; };
+    struct Case { const char* name; int ww, wh, lds_words, sites; int interleave; int copies; int pattern = 0; };   // pattern 1 / 2: see below
     const Case cases[] = {
         {"46x46 window, 18 KB LDS (8 WG/CU), uniform centres", 46, 46, 4608, 0, 0, 1},
         {"46x46 window, 36 KB LDS (4 WG/CU), uniform centres", 46, 46, 9216, 0, 0, 1},
@@ -60,6 +60,13 @@ int main() {
         {"46x46 window, 100 sites, 18 KB LDS", 46, 46, 4608, 100, 0, 1},
         {"46x46 window, 100 sites, 2 copies (36 KB LDS)", 46, 46, 9216, 100, 0, 2},
         {"46x46 window, 1000 sites, 18 KB LDS", 46, 46, 4608, 1000, 0, 1},
+        // round 3: would a row pitch of 64 words with 32 DISTINCT columns per half-wave (bank = column) pay?  (pattern 1; 2 = the control:
+        // the same pitch, random columns; 3 = distinct columns with a +-1 jitter on 30 % of the lanes, as rounding produces)
+        {"64-word pitch, 36 rows, 32 distinct columns per half-wave", 64, 36, 4608, 0, 0, 1, 1},
+        {"64-word pitch, 36 rows, random columns of 32 (control)", 64, 36, 4608, 0, 0, 1, 2},
+        {"64-word pitch, 36 rows, distinct columns, +-1 jitter on 30 %", 64, 36, 4608, 0, 0, 1, 3},
+        {"64-word pitch, distinct columns, math between the atomics", 64, 36, 4608, 0, 1, 1, 1},
+        {"64-word pitch, random columns, math between the atomics", 64, 36, 4608, 0, 1, 1, 2},
     };
     for (const Case& c : cases) {
         srand(3);
@@ -67,6 +74,18 @@ int main() {
         for (int& s : sites) s = (rand() % (c.wh - 2)) * c.ww + rand() % (c.ww - 2);
         for (size_t i = 0; i < n; ++i)
             h[i] = c.sites > 0 ? sites[rand() % c.sites] : (rand() % (c.wh - 2)) * c.ww + rand() % (c.ww - 2);
+        if (c.pattern) {
+            int perm[32];
+            for (size_t i = 0; i < n; i += 32) {            // 32 consecutive lanes = one half-wave of one trip
+                for (int k = 0; k < 32; ++k) perm[k] = k;
+                for (int k = 31; k > 0; --k) { const int j = rand() % (k + 1); const int t = perm[k]; perm[k] = perm[j]; perm[j] = t; }
+                for (int k = 0; k < 32 && i + k < n; ++k) {
+                    int x = 8 + (c.pattern == 2 ? rand() % 32 : perm[k]);              // columns 8..39 of the 64-word rows
+                    if (c.pattern == 3 && rand() % 10 < 3) x += (rand() & 1) ? 1 : -1;
+                    h[i + k] = (rand() % (c.wh - 2)) * c.ww + x;
+                }
+            }
+        }
         CHK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
         hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
         const size_t lds_bytes = (size_t)c.lds_words * 4;
