@@ -440,8 +440,9 @@ def bench_windows(a):
                      'lds_atomic_lane_ops_per_clk_per_cu': (9.0 * B * N * R / (kern['k_splat']['avg_launch_ms'] * 1e-3) / 256 / 2.4e9)
                      if kern['k_splat']['avg_launch_ms'] > 0 else 0.0,
                      'lds_atomic_peak_lane_ops_per_clk_per_cu': [5.9, 7.4],
-                     'lds_atomic_note': '9 ds_add_u32 per warped event; peak = tools/lds_atomic_bench2.hip with the splat\'s own tap pattern '
-                                        '(destinations on 300 sites, uniform destinations), profiles/r02/splat_bound_experiment.txt'})
+                     'lds_atomic_note': '9 ds_add_u32 per warped event; peak = tools/lds_atomic_bench2.hip with the splat\'s own tap pattern at a 64-word '
+                                        'row pitch: random columns, 32 distinct columns per half-wave (profiles/r03/lds_bank_pitch.txt); the kernel '
+                                        'is VALU-bound, so this rate is what its arithmetic leaves room for, not what the LDS could do'})
         out = {
             'metric': 'warped-events/sec/GPU + loss+grad eval ms, 1e6 events @ 346x260',
             'value': value, 'unit': 'warped-events/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,

@@ -702,15 +702,24 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         warp_axis(x, v.x, dt, irx, fx);
         warp_axis(y, v.y, dt, iry, fy);
         f2v km, k0, kp;                              // .x = x-axis weight, .y = y-axis weight (scaled)
+#ifdef EINCM_ABL_S_NOMATH                            // timing-only: the atomics at their real addresses, no tap arithmetic
+        km.x = km.y = k0.x = k0.y = kp.x = kp.y = 3.0f;
+#else
         taps3x2(fx, fy, scy, km, k0, kp);
+#endif
         const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;        // window coords of the top-left tap
         if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
             uint32_t* p = ldsu + __mul24(ly, wp) + lx;
             // 3x3 products ky[dy]*kx[dx] + 0.5 (scalar FMAs: packed ones are slower on gfx950), then truncating converts
             uint32_t* p1 = p + wp; uint32_t* p2 = p1 + wp;
+#ifdef EINCM_ABL_S_NOATOMIC                          // timing-only: all the arithmetic, one plain store instead of nine atomics
+            *p = fix_u32(km.y, km.x) + fix_u32(km.y, k0.x) + fix_u32(km.y, kp.x) + fix_u32(k0.y, km.x) + fix_u32(k0.y, k0.x) + fix_u32(k0.y, kp.x)
+               + fix_u32(kp.y, km.x) + fix_u32(kp.y, k0.x) + fix_u32(kp.y, kp.x) + (uint32_t)(p1 - p2);
+#else
             atomicAdd(p, fix_u32(km.y, km.x)); atomicAdd(p + 1, fix_u32(km.y, k0.x)); atomicAdd(p + 2, fix_u32(km.y, kp.x));
             atomicAdd(p1, fix_u32(k0.y, km.x)); atomicAdd(p1 + 1, fix_u32(k0.y, k0.x)); atomicAdd(p1 + 2, fix_u32(k0.y, kp.x));
             atomicAdd(p2, fix_u32(kp.y, km.x)); atomicAdd(p2 + 1, fix_u32(kp.y, k0.x)); atomicAdd(p2 + 2, fix_u32(kp.y, kp.x));
+#endif
         } else {
             const float kx[3] = {km.x, k0.x, kp.x}, ky[3] = {km.y, k0.y, kp.y};
             const int sx = clamp_far(irx), sy = clamp_far(iry), lxs = sx - 1 - wn.ox, lys = sy - 1 - wn.oy;
