@@ -300,18 +300,18 @@ __device__ __forceinline__ int clamp_far(int ir) { return min(max(ir, -(1 << 20)
 struct f2v { float x, y; };
 
 // Separable 3-tap weights of BOTH axes: k(d) = exp(-0.5 (d - f)^2) = exp(-0.5 f^2) exp(d f) exp(-0.5 d^2),
-// d = -1, 0, 1 (event_utils.py:52-56).  The y weights carry `scale_y` (1/(2 pi), times the fixed-point scale in k_splat).
-// 4 v_exp_f32 + 2 v_rcp_f32 (1 ulp each) + 13 multiplies.
+// d = -1, 0, 1 (event_utils.py:52-56), normalised to the centre tap: per axis (a, 1, b) with b = exp(f - 1/2), a = exp(-f - 1/2) = e^-1 / b;
+// the common factor exp(-(fx^2 + fy^2) / 2) * scale_y (1/(2 pi), times the fixed-point scale in k_splat) rides on the y weights.
+// 3 v_exp_f32 + 2 v_rcp_f32 (1 ulp each) + 10 multiply-adds (the unnormalised form took 4 + 2 + 13: k_splat is bound by VALU issue).
 __device__ __forceinline__ void taps3x2(float fx, float fy, float scale_y, f2v& km, f2v& k0, f2v& kp) {
-    constexpr float L2E = 1.4426950408889634f;
-    const float e0x = __builtin_amdgcn_exp2f((fx * fx) * (-0.5f * L2E));
-    const float e0y = __builtin_amdgcn_exp2f((fy * fy) * (-0.5f * L2E)) * scale_y;
-    const float epx = __builtin_amdgcn_exp2f(fx * L2E), epy = __builtin_amdgcn_exp2f(fy * L2E);
-    const float emx = __builtin_amdgcn_rcpf(epx), emy = __builtin_amdgcn_rcpf(epy);
-    const float cx = e0x * EXP_M05, cy = e0y * EXP_M05;
-    km.x = cx * emx; km.y = cy * emy;            // d = -1
-    k0.x = e0x; k0.y = e0y;
-    kp.x = cx * epx; kp.y = cy * epy;            // d = +1
+    constexpr float L2E = 1.4426950408889634f, EXP_M1 = 0.36787944117144233f;
+    const float bx = __builtin_amdgcn_exp2f(fmaf(fx, L2E, -0.5f * L2E)), by = __builtin_amdgcn_exp2f(fmaf(fy, L2E, -0.5f * L2E));
+    const float ax = EXP_M1 * __builtin_amdgcn_rcpf(bx), ay = EXP_M1 * __builtin_amdgcn_rcpf(by);
+    // (the scale is multiplied on, not folded into the exponent: exp2 of an argument of ~21 would lose five bits of the fraction)
+    const float s = __builtin_amdgcn_exp2f(fmaf(fx, fx, fy * fy) * (-0.5f * L2E)) * scale_y;
+    km.x = ax; km.y = s * ay;                    // d = -1
+    k0.x = 1.0f; k0.y = s;
+    kp.x = bx; kp.y = s * by;                    // d = +1
 }
 
 struct EvReg { uint32_t xy; double t; };   // one event in flight through the software pipeline of the event kernels
