@@ -321,8 +321,11 @@ struct EvReg { uint32_t xy; double t; };   // one event in flight through the so
 constexpr int THETA_CONST = 1;   // theta (1,1,2): Theta is one constant per window (read from the tile bounds, min == max)
 constexpr int THETA_TILE = 2;    // otherwise: the tile's 32x32 double2 velocities are staged in LDS once per segment (16 KiB)
 
-// round-to-nearest fixed-point conversion of a positive value: fma + truncating convert (2 instructions)
-__device__ __forceinline__ uint32_t fix_u32(float a, float b) { return (uint32_t)fmaf(a, b, 0.5f); }
+// round-to-nearest fixed-point conversion of a positive product < 2^31: v_mul_f32 + v_cvt_rpi_i32_f32 (floor(x + 0.5) in the converter itself;
+// the compiler has no builtin for it).  Where b is the constant 1 (the centre column of the normalised taps) the multiply folds away: one
+// instruction instead of the add + truncating convert of (uint32_t)(a + 0.5f) - k_splat is bound by VALU issue.
+__device__ __forceinline__ uint32_t cvt_rpi(float x) { uint32_t r; asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ uint32_t fix_u32(float a, float b) { return cvt_rpi(a * b); }
 
 // The rows of A_H and the columns of A_W that one 32x32 tile needs, staged in LDS by the whole workgroup (k_theta, k_project).
 // Per-pixel reads of the tap ranges and weights from global memory were chains of dependent loads: 12 us of k_theta and 18-30 us
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         wn = wins[(size_t)item * g.R + r];
     }
     const int nwin = wn.ww * wn.wh;
-    const int wp = MERGE ? wn.ww : win_pitch(wn.ww), nlds = wp * wn.wh;     // LDS row pitch and words (win_pitch; the MERGE experiment walks the
+    const int wp = MERGE ? wn.ww : win_pitch(wn.ww), wp4 = wp * 4, nlds = wp * wn.wh;     // LDS row pitch and words (win_pitch; the MERGE experiment walks the
                                                                             // gather's list, whose window table is sized for pitch = width)
     const bool multi = MULTI != 0 && it.count > chunk;       // MULTI == 0: the commit logic in the loop folds away
     {   // clear the window(s), 16 B per lane
@@ -709,7 +712,8 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
 #endif
         const int lx = irx - 1 - wn.ox, ly = iry - 1 - wn.oy;        // window coords of the top-left tap
         if ((unsigned)lx < (unsigned)(wn.ww - 2) && (unsigned)ly < (unsigned)(wn.wh - 2)) {
-            uint32_t* p = ldsu + __mul24(ly, wp) + lx;
+            // byte offsets with the row pitch pre-scaled (a scalar): one v_mul_i32_i24 + one v_lshl_add_u32, then one add per further row
+            uint32_t* p = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ldsu) + (__mul24(ly, wp4) + (lx << 2)));
             // 3x3 products ky[dy]*kx[dx] + 0.5 (scalar FMAs: packed ones are slower on gfx950), then truncating converts
             uint32_t* p1 = p + wp; uint32_t* p2 = p1 + wp;
 #ifdef EINCM_ABL_S_NOATOMIC                          // timing-only: all the arithmetic, one plain store instead of nine atomics
