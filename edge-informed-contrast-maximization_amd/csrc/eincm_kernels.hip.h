@@ -264,7 +264,8 @@ __device__ __forceinline__ Window item_window(const Geom& g, const Item& it, con
     int by0 = y0 + (int)lo[1] - 2, by1 = y1 + (int)hi[1] + 2;
     int ww = bx1 - bx0 + 1, wh = by1 - by0 + 1;
     if ((aligned ? win_pitch(ww) : ww) * wh > wincap || ww > winmaxw) {          // (LDS holds pitch x wh words)
-        const int nww = min(ww, winmaxw);
+        int nww = min(ww, winmaxw);
+        if (aligned && nww >= 64) nww &= ~31;        // a clamped wide window: a whole number of 32-word bank rows, so that no LDS is pitch padding
         const int nwh = min(wh, wincap / (aligned ? win_pitch(nww) : nww));
         bx0 = (bx0 + bx1) / 2 - nww / 2;
         by0 = (by0 + by1) / 2 - nwh / 2;
