@@ -695,7 +695,13 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
     // Software pipeline over the segment's events, unrolled x3 with renamed register sets (no rotation moves, so no forced
     // vmcnt(0)): the (xy, t) loads of event j+2 are in flight while event j is splatted.
     const int tid = threadIdx.x;
+#if defined(EINCM_ABL_S_NOLOADT)                  // timing-only: no 8-byte timestamp load (what the event traffic from L2 costs)
+    auto load_ev = [&](EvReg& r, int e) { if (e < n) { r.xy = exy[e]; r.t = it.t_lo + 1e-9 * (double)e; } else { r.xy = 0u; r.t = 0.0; } };
+#elif defined(EINCM_ABL_S_NOLOAD)                 // timing-only: no event loads at all
+    auto load_ev = [&](EvReg& r, int e) { r.xy = ((uint32_t)(ty0 + ((e * 7) & 31)) << 16) | (uint32_t)(tx0 + (e & 31)); r.t = it.t_lo + 1e-9 * (double)e; };
+#else
     auto load_ev = [&](EvReg& r, int e) { if (e < n) { r.xy = exy[e]; r.t = et[e]; } else { r.xy = 0u; r.t = 0.0; } };
+#endif
     const float scy = INV_2PI * FIX_SCALE;          // one fixed-point scale per segment: every chunk holds <= min(chunk, n) events
     auto splat_ev = [&](const EvReg& ev) {
         const double dt = ev.t - tau;
