@@ -1342,7 +1342,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     c->seg_used = seg;
     // (late round 3: k_splat is no longer bound by the LDS atomic unit, so its per-workgroup fixed work - 24 of 90 us on the 8-window
     // batch: window derivation and clear 14, flush 10 - shows: 16384-event segments there, 90.1 -> 85.2 us; 104 -> 100 us at 16x16)
-    int seg_s = c->seg_s > 0 ? c->seg_s : (x_wg >= 4000.0 ? 16384 : (x_wg >= 400.0 ? 8192 : 4096));     // one window at R = 1: 4096 (0.066 vs 0.075 ms per evaluation)
+    int seg_s = c->seg_s > 0 ? c->seg_s : (x_wg >= 3000.0 ? 16384 : (x_wg >= 400.0 ? 8192 : 4096));     // (4 windows of 10^6 events: 52.4 -> 49.7 us; 2 windows: equal; 1: 18.8 vs 19.7 the other way)  one window at R = 1: 4096 (0.066 vs 0.075 ms per evaluation)
     c->seg_s_used = seg_s;
     const bool sort_segments = getenv("EINCM_NO_SEGSORT") == nullptr;
     if (!c->chunk_fixed) c->chunk = std::max(4096, std::min(seg_s, MAX_CHUNK));     // single-chunk segments: no f32 commit pass
