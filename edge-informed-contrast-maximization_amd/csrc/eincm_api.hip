@@ -839,7 +839,13 @@ int eval_end_launch(eincm_ctx* c) {
                 const double* t_g = direct11 ? c->d_t : c->d_t_g;
                 Geom gg = g;
                 if (direct11) { gg.wincap_a = c->wincap_2; gg.winmaxw_a = std::max(40, (int)std::lround(std::sqrt((double)c->wincap_2 * 1.4))); }
-                const unsigned grid_g = (unsigned)(((n_g + NXCD - 1) / NXCD) * NXCD * g.R);
+                // theta grids with the in-gather projection on big launches: one workgroup per segment for all reference times (k_gather, all_r)
+                static const int all_r_env = getenv("EINCM_GATHER_ALL_R") ? atoi(getenv("EINCM_GATHER_ALL_R")) : -1;
+                // (8 windows of 10^6 events at 16x16: 792 workgroups of 5 reference times each instead of 3960: 148 -> 135 us; one window:
+                // 99 workgroups, 29 -> 84 us - so only where the segments alone fill the chip's 768 workgroup slots of this kernel)
+                int all_r = (!direct11 && proj && !compose && !identity && n_g >= 700) ? 1 : 0;
+                if (all_r_env >= 0) all_r = (all_r_env && !direct11 && proj && !compose && !identity) ? 1 : 0;
+                const unsigned grid_g = (unsigned)(((n_g + NXCD - 1) / NXCD) * NXCD * (all_r ? 1 : g.R));
                 // 2-DoF theta: workgroups per segment, so that a workgroup takes about what the round-2 tuning found best for this
                 // kernel (4096 events on one window, 16384 on the 8-window batch) whatever the segment length of the list
                 int nparts = 1;
@@ -858,12 +864,15 @@ int eval_end_launch(eincm_ctx* c) {
                     ep.contrast_kind == EINCM_CONTRAST_GRAD_MAG ? 1 : 0, c->d_edges, c->d_iwe, c->d_coef, c->d_acc, 1, nparts, \
                     h, w, c->d_AH, c->d_AW, c->d_tilerng, c->d_gth, (int)c->coarse_cap, \
                     (host_asm && proj) ? 1 : 0, c->d_gticket, c->d_win_item0, c->h_grad, \
-                    (host_asm && proj && ep.use_tv_grad) ? ep.gamma : 0.0, c->d_tvparts, c->d_gth + (size_t)c->maxB * c->coarse_cap
+                    (host_asm && proj && ep.use_tv_grad) ? ep.gamma : 0.0, c->d_tvparts, c->d_gth + (size_t)c->maxB * c->coarse_cap, all_r
 #define GATHER_TILE(WIDE_, COMPOSE_, PROJ_) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, WIDE_, NT_TILE, COMPOSE_, PROJ_>, GATHER_ARGS(NT_TILE))
+#define GATHER_ALLR(WIDE_) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_TILE, WIDE_, NT_TILE, 0, 1, 1>, GATHER_ARGS(NT_TILE))
                 if (direct11) {
                     if (compose) launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 1, 0>, GATHER_ARGS(NT));
                     else         launch_timed(c, EINCM_STAGE_GATHER, k_gather<THETA_CONST, 0, NT, 0, 0>, GATHER_ARGS(NT));
                     c->g11_per_item = g.R * nparts;
+                } else if (all_r) {
+                    if (wide) GATHER_ALLR(1); else GATHER_ALLR(0);
                 } else if (wide) {
                     if (compose) { if (proj) GATHER_TILE(1, 1, 1); else GATHER_TILE(1, 1, 0); }
                     else         { if (proj) GATHER_TILE(1, 0, 1); else GATHER_TILE(1, 0, 0); }
@@ -872,6 +881,7 @@ int eval_end_launch(eincm_ctx* c) {
                     else         { if (proj) GATHER_TILE(0, 0, 1); else GATHER_TILE(0, 0, 0); }
                 }
 #undef GATHER_TILE
+#undef GATHER_ALLR
 #undef GATHER_ARGS
             }
         }

@@ -1677,8 +1677,8 @@ __device__ __forceinline__ void project_tile_to_cells(const Geom& g, int h, int 
         if (ay != 0.0) atomicAdd(o + 1, (unsigned long long)fix64_wide(ay));
     }
 }
-template <int TM, int WIDE, int NTH, int COMPOSE, int PROJ>      // NTH threads per workgroup: 256, or 512 where the LDS footprint allows only 3 workgroups per CU (THETA_TILE); TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
-__global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WIDE: 61-bit fixed point per event (tiny windows, see grad_shift_pixel)
+template <int TM, int WIDE, int NTH, int COMPOSE, int PROJ, int ALLR = 0>      // NTH threads per workgroup: 256, or 512 where the LDS footprint allows only 3 workgroups per CU (THETA_TILE); TM: the theta mode as a compile-time constant (THETA_CONST / THETA_TILE); 0 = take the run-time argument
+__global__ __launch_bounds__(NTH, (ALLR ? 6 : 1)) void k_gather(Geom g, int n_items,      // WIDE: 61-bit fixed point per event (tiny windows, see grad_shift_pixel)
         const Item* __restrict__ items, const uint32_t* __restrict__ ev_xy, const double* __restrict__ ev_t,
         const double* __restrict__ Theta, const double* __restrict__ tmm, const double* __restrict__ edge_ts,
         const float* __restrict__ G,           // (B,R,H,W) dL/dIWE written by k_imgrad (COMPOSE = 0), or the A image of k_imstat (COMPOSE = 1)
@@ -1702,7 +1702,9 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         // tail (PROJ only, tail != 0): the workgroup of a window that finishes LAST turns the window's i64 cell sums into dL/dtheta and
         // writes it where the host reads it - what k_final did in a launch of its own (7-8 us of a 65 us evaluation)
         int tail, unsigned* __restrict__ ticket, const int32_t* __restrict__ win_item0, double* __restrict__ grad_out,
-        double tv_gamma, const double* __restrict__ tvparts, long long* __restrict__ gth_tv)   // tail with the TV term (gamma != 0 at level 0)
+        double tv_gamma, const double* __restrict__ tvparts, long long* __restrict__ gth_tv,   // tail with the TV term (gamma != 0 at level 0)
+        int all_r_unused)   // (ALLR = 1, theta grids on big batches: ONE workgroup per segment walks all R reference times - grid = segments,
+                     // not segments x R -, so that the Theta tile, the accumulator clear, the projection and the ticket are paid once per segment)
 {
     const int part = blockIdx.y;
     if (TM != 0) theta_mode = TM;                 // every branch on it below folds away: 8 % on both event kernels
@@ -1723,10 +1725,11 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         for (size_t i = lo + threadIdx.x; i < hi; i += NTH) acc[i] = 0ull;
     }
     int item, r;
-    if (!block_to_work(n_items, g.R, order, item, r)) return;
+    constexpr bool all_r = ALLR != 0;
+    if (!block_to_work(n_items, all_r ? 1 : g.R, order, item, r)) return;
     const Item it = items[item];
     if (!win_active(g, it.win)) return;
-    const double tau = edge_ts[it.win * g.R + r];
+    double tau = edge_ts[it.win * g.R + r];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool gradmag = gradmag_i != 0;
     double2 vconst = make_double2(0.0, 0.0);
@@ -1738,8 +1741,8 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
     } else {
         wn = wins[(size_t)item * g.R + r];
     }
-    const int wp = (theta_mode == THETA_CONST) ? win_pitch(wn.ww) : wn.ww;      // LDS row pitch of the G window (see item_window)
-    const size_t img = ((size_t)it.win * g.R + r) * g.H * g.W;
+    int wp = (theta_mode == THETA_CONST) ? win_pitch(wn.ww) : wn.ww;      // LDS row pitch of the G window (see item_window)
+    size_t img = ((size_t)it.win * g.R + r) * g.H * g.W;
     const float* __restrict__ Gi = G + img;
     const float* __restrict__ Ei = edges + img;
     const float* __restrict__ Ii = iwe + img;
@@ -1764,6 +1767,7 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         if (!COMPOSE) return Gi[p];
         return compose_G(q, gradmag, gradmag ? Gi[p] : 0.0f, Ei[p], Ii[p]);
     };
+    auto load_window = [&]() {                    // the G window of the current reference time into LDS
     if (wn.ox >= 0 && wn.oy >= 0 && wn.ox + wn.ww <= g.W && wn.oy + wn.wh <= g.H) {      // the usual case: window inside the image
         const size_t o0 = (size_t)wn.oy * g.W + wn.ox;
         for (WinWalkT<NTH> w(threadIdx.x, wn.ww); w.i < wn.ww * wn.wh; w.next()) lds[w.row * wp + w.col] = G_at(o0 + w.row * g.W + w.col);
@@ -1776,6 +1780,8 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
             }
         }
     }
+    };
+    load_window();
     double gscale = 0.0;                          // 2^eg of this window's gradient accumulators
     double gm_used = 0.0;                         // max |G| (or its bound) the scales derive from
     if (!direct11) {
@@ -1854,14 +1860,25 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
             gather_ev(ev);
         }
     };
+    for (int rr = r; ; ) {                        // one reference time, or all of them (all_r)
 #ifndef EINCM_ABL_G_NOEVENTS
     // nparts > 1 (2-DoF theta, few windows): a segment is shared by nparts workgroups (blockIdx.y), so that the segments can be long
     // (what the theta-grid gather wants from the one list both walk) and the chip still sees enough workgroups
     if (NTH == 512) walk_half(walk.half, 0, 1);
     else if (nparts == 1) { walk_half(0, 0, 1); walk_half(1, 0, 1); }
     else { const int nsub = nparts >> 1; walk_half(part / nsub, part % nsub, nsub); }
-    if (!direct11) flush_run();
+    if (!direct11) { flush_run(); cur_key = 0xffffffffu; run_x = 0.0; run_y = 0.0; }
 #endif
+    if (!all_r || ++rr >= g.R) break;
+    __syncthreads();                              // every lane is done with the G window of the previous reference time
+    tau = edge_ts[it.win * g.R + rr];
+    wn = wins[(size_t)item * g.R + rr];
+    wp = wn.ww;
+    img = ((size_t)it.win * g.R + rr) * g.H * g.W;
+    Gi = G + img; Ei = edges + img; Ii = iwe + img;
+    load_window();
+    __syncthreads();
+    }
     if (direct11) {
         double sum11x = block_sum<NTH / 64>((double)f11x, red11);
         double sum11y = block_sum<NTH / 64>((double)f11y, red11);
@@ -1899,7 +1916,7 @@ __global__ __launch_bounds__(NTH) void k_gather(Geom g, int n_items,      // WID
         if (threadIdx.x == 0) {
             const int n_it = ((it.win + 1 < g.B) ? win_item0[it.win + 1] : n_items) - win_item0[it.win];
             const unsigned old = __hip_atomic_fetch_add(ticket + it.win, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool last = old == (unsigned)(n_it * g.R) - 1u;
+            const bool last = old == (unsigned)(n_it * (all_r ? 1 : g.R)) - 1u;
             if (last) __hip_atomic_store(ticket + it.win, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = last ? 1 : 0;
         }

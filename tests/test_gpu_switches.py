@@ -26,6 +26,7 @@ SWITCHES = [
     ({'EINCM_SEG': '4096', 'EINCM_SEG_SPLAT': '2048', 'EINCM_SEG_2DOF': '8192'}, 'other segment lengths'),
     ({'EINCM_GATHER_PARTS': '2'}, '2-DoF gather segments shared by two workgroups'),
     ({'EINCM_HOST_BINNING': '1'}, 'host-side counting sort'),
+    ({'EINCM_GATHER_ALL_R': '1'}, 'theta-grid gather: one workgroup per segment walks all reference times'),
 ]
 
 
