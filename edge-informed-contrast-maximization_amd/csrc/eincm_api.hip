@@ -71,6 +71,8 @@ struct eincm_ctx {
     // third list: the segments the 2-DoF gather walks, on the SPLAT's copy of the events (it has no per-pixel accumulators, so the
     // time-ordered copy serves it, and it wants shorter segments than the theta-grid gather does: round-2 tuning)
     Item* d_items_2 = nullptr; int32_t* d_order_2 = nullptr; int32_t* d_win_item0_2 = nullptr;
+    Item* d_items_sh = nullptr; int32_t* d_order_sh = nullptr; int n_items_sh = 0; int seg_sh_used = 0;   // the splat's SHORT list (8192) beside a 16384-event
+                                                                       // one: a 2-DoF theta too large for the long segments' windows walks it (launch_forward)
     int n_items_2 = 0; int seg_2_used = 0;
     std::vector<int32_t> h_order_2, h_win_item0_2;
     int wincap_2 = WIN_CAP_DEFAULT;
@@ -177,6 +179,7 @@ struct eincm_ctx {
     int last_nparts = 0;           // how many StatParts per image the last evaluation wrote (k_stats vs k_stats_stream)
     // an evaluation split in two halves (eval_begin ... [caller may all-reduce the IWE stack] ... eval_end)
     struct { bool active = false; bool launched = false; EvalParams ep{}; int h = 0, w = 0; bool identity = false, want_grad = false, full_aux = false, div_grad = false;
+             bool splat_short = false;              // this evaluation's k_splat walks the short segment list (d_items_sh)
              bool host_asm = false;                 // scalar assembly and the 2-DoF gradient sum on the host (see h_g11)
              bool composed = false;                 // k_imstat + composing gather (host_assemble: the contrast energy rides in h_img)
              bool tv_projected = false;             // k_tv projected its gradient onto the theta cells itself (no k_project for it)
@@ -283,7 +286,7 @@ void multi_ref_weights(int R, double* w) {
 
 void free_all(eincm_ctx* c) {
     auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(c->d_xy); F(c->d_t); F(c->d_xy_g); F(c->d_t_g); F(c->d_items); F(c->d_items_s); F(c->d_items_2); F(c->d_order_2); F(c->d_win_item0_2); F(c->d_order); F(c->d_order_s); F(c->d_wins); F(c->d_wins_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
+    F(c->d_xy); F(c->d_t); F(c->d_xy_g); F(c->d_t_g); F(c->d_items); F(c->d_items_s); F(c->d_items_2); F(c->d_order_2); F(c->d_win_item0_2); F(c->d_items_sh); F(c->d_order_sh); F(c->d_order); F(c->d_order_s); F(c->d_wins); F(c->d_wins_s); F(c->d_raw_x); F(c->d_raw_y); F(c->d_raw_t); F(c->d_binblocks); F(c->d_win_blk);
     F(c->d_blockhist); F(c->d_tilecount); F(c->d_tilebase); F(c->d_itembase); F(c->d_itembase_s); F(c->d_bin_misc); F(c->d_edges_raw); F(c->d_edge_moments); F(c->d_edges); F(c->d_edge_ts); F(c->d_acc); F(c->d_iwe); F(c->d_G); F(c->d_zero_iwe);
     F(c->d_g11); F(c->d_win_item0); F(c->d_dtmax); F(c->d_gmax); F(c->d_cntmax); F(c->d_amax); F(c->d_gbound); F(c->d_ticket); F(c->d_gticket); F(c->d_coef); F(c->d_Gimg);
     F(c->d_Theta); F(c->d_theta_in); F(c->d_gTheta); F(c->d_tvg); F(c->d_mask); F(c->d_tmm); F(c->d_parts);
@@ -527,8 +530,13 @@ int launch_forward(eincm_ctx* c, int h, int w, bool identity, bool need_theta_im
             const int lds_multi = (c->seg_s_used > c->chunk) ? 1 : 0;      // segments longer than a chunk need the f32 commit window
             const size_t lds_bytes = (size_t)(lds_multi ? 2 : 1) * g.wincap * sizeof(float)
                                    + (theta_mode == THETA_TILE ? TS * TS * sizeof(double2) : 0);
-#define SPLAT_ARGS(NTH) dim3(splat_grid(c)), dim3(NTH), lds_bytes, g, c->n_items_s, c->chunk, theta_mode, lds_multi, \
-                   c->d_items_s, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wins_s, c->d_acc, c->d_order_s, \
+            const bool sshort = c->pend.splat_short && const_theta;
+            const int n_sp = sshort ? c->n_items_sh : c->n_items_s;
+            const Item* items_sp = sshort ? c->d_items_sh : c->d_items_s;
+            const int32_t* order_sp = sshort ? c->d_order_sh : c->d_order_s;
+            const unsigned grid_sp = (unsigned)(((n_sp + NXCD - 1) / NXCD) * NXCD * g.R);
+#define SPLAT_ARGS(NTH) dim3(grid_sp), dim3(NTH), lds_bytes, g, n_sp, c->chunk, theta_mode, lds_multi, \
+                   items_sp, c->d_xy, c->d_t, c->d_Theta, c->d_tmm, c->d_edge_ts, c->d_wins_s, c->d_acc, order_sp, \
                    use_arg ? 1 : 0, theta_dev, targ
             static const bool merge_env = getenv("EINCM_SPLAT_MERGE") != nullptr;
             if (merge_env && !lds_multi && c->seg_used <= MAX_CHUNK && c->n_items > 0) {
@@ -640,6 +648,7 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
 
     // LDS window capacity for this evaluation: the host knows theta, hence the largest displacement a segment can see.
     // Small windows give 8 workgroups per CU; windows too small for the flow push taps onto the slow direct-to-HBM path.
+    c->pend.splat_short = false;
     if (!c->wincap_fixed) {
         double vmax = 0.0;
         const size_t nall = (size_t)g.B * nth;
@@ -651,8 +660,15 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         const double tspan = std::min(1.0, (double)c->seg_s_used / std::max(per_tile, 1.0));
         // LDS holds pitch x height words per window, the pitch being the width rounded up to the 32 banks (win_pitch)
         auto lds_words = [](double side_px) { const double sd = std::ceil(side_px); return std::ceil(sd / 32.0) * 32.0 * sd; };
-        const double side = TS + 4 + vmax * tspan;
-        const double need = lds_words(side);
+        double side = TS + 4 + vmax * tspan;
+        double need = lds_words(side);
+        // a 2-DoF theta whose spread over a long splat segment outgrows the largest window: the short list (half the time span); the taps
+        // of a window that is too small go to HBM one by one (117 px per window: 1220 us on the long list, 544 us on the short one)
+        c->pend.splat_short = (h == 1 && w == 1 && !identity && c->n_items_sh > 0 && need > 6912.0);
+        if (c->pend.splat_short) {
+            side = TS + 4 + vmax * std::min(1.0, (double)c->seg_sh_used / std::max(per_tile, 1.0));
+            need = lds_words(side);
+        }
         static const int caps[] = {2304, 3072, 4608, 6912};      // 6912 keeps k_gather's LDS (window + accumulators + Theta tile) under 64 KiB
         int cap = caps[3];
         for (int k = 0; k < 4; ++k) if (need <= caps[k]) { cap = caps[k]; break; }
@@ -1196,6 +1212,8 @@ eincm_ctx* eincm_create(int device, int H, int W, int max_refs, int max_windows,
     TRY(dalloc(&c->d_order, (size_t)c->max_items));
     TRY(dalloc(&c->d_order_s, (size_t)c->max_items));
     TRY(dalloc(&c->d_items_2, (size_t)c->max_items));
+    TRY(dalloc(&c->d_items_sh, (size_t)c->max_items));
+    TRY(dalloc(&c->d_order_sh, (size_t)c->max_items));
     TRY(dalloc(&c->d_order_2, (size_t)c->max_items));
     TRY(dalloc(&c->d_win_item0_2, B + 1));
     TRY(dalloc(&c->d_wins, (size_t)c->max_items * max_refs));
@@ -1619,6 +1637,22 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             hipLaunchKernelGGL(k_seg_minmax, dim3((unsigned)std::min<size_t>(items_2.size(), 4096)), dim3(NT), 0, c->stream, (int)items_2.size(), c->d_items_2, c->d_t);
         }
         HIPCHK(c, hipMemcpyAsync(c->d_win_item0_2, c->h_win_item0_2.data(), (size_t)(n_windows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
+    std::vector<Item> items_sh;
+    std::vector<int32_t> order_sh;
+    c->n_items_sh = 0; c->seg_sh_used = 0;
+    if (seg_s > 8192) {   // the splat's short list: the same events cut into 8192-event segments, for evaluations whose theta is too large for
+        std::vector<int32_t> w0;                    // the windows of the long segments (twice the time span, hence twice the spread)
+        host_items(c->h_tilecount, g.ntiles, 8192, items_sh, w0);
+        if ((int64_t)items_sh.size() <= c->max_items && !items_sh.empty()) {
+            std::vector<int32_t> lens(items_sh.size());
+            for (size_t i = 0; i < items_sh.size(); ++i) lens[i] = items_sh[i].count;
+            order_by_length(lens, order_sh);
+            HIPCHK(c, hipMemcpyAsync(c->d_items_sh, items_sh.data(), items_sh.size() * sizeof(Item), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_order_sh, order_sh.data(), order_sh.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_seg_minmax, dim3((unsigned)std::min<size_t>(items_sh.size(), 4096)), dim3(NT), 0, c->stream, (int)items_sh.size(), c->d_items_sh, c->d_t);
+            c->n_items_sh = (int)items_sh.size(); c->seg_sh_used = 8192;
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_items_2 = (int)items_2.size();
