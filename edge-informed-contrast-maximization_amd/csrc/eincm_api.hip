@@ -654,6 +654,7 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         const size_t nall = (size_t)g.B * nth;
         const size_t stride = nall > 8192 ? nall / 8192 : 1;            // dense theta: sample (any capacity is correct; 65536 samples cost 90 us)
         if (c->theta_dev_in) vmax = (c->vmax_hint >= 0.0 && std::isfinite(c->vmax_hint)) ? c->vmax_hint : 1e9;      // unknown: the largest windows
+        else if (stride == 1) { for (size_t i = 0; i < nall; ++i) { const double a = std::fabs(theta_host[i]); vmax = std::max(vmax, a <= 1.7e308 ? a : 0.0); } }   // (vectorises)
         else for (size_t i = 0; i < nall; i += stride) { const double a = std::fabs(theta_host[i]); if (a > vmax && std::isfinite(a)) vmax = a; }
         // time span of a typical splat segment: seg_s events out of the average tile population
         const double per_tile = (double)std::max<int64_t>(c->n_events, 1) / ((double)g.B * g.ntiles);
@@ -703,10 +704,15 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
                           !c->device_results && !c->theta_dev_in;
     if (host_asm) {
         c->theta_nan.assign((size_t)g.B, 0);
-        for (int b = 0; b < g.B; ++b) {
-            bool bad = false;
-            for (size_t i = 0; i < nth; ++i) bad = bad || !std::isfinite(theta_host[(size_t)b * nth + i]);
-            c->theta_nan[b] = bad;
+        for (int b = 0; b < g.B; ++b) {            // branch-free (vectorises): an OR over the exponent bits, 4096 values at 16x16 x 8 windows
+            const double* __restrict__ tb = theta_host + (size_t)b * nth;
+            uint64_t bad = 0;
+            for (size_t i = 0; i < nth; ++i) {
+                uint64_t u;
+                memcpy(&u, tb + i, sizeof u);
+                bad |= (uint64_t)((u & 0x7ff0000000000000ull) == 0x7ff0000000000000ull);
+            }
+            c->theta_nan[b] = bad != 0;
         }
     }
     int rc = launch_forward(c, h, w, identity, ep.want_tv != 0, theta_host, host_asm);
