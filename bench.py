@@ -435,13 +435,13 @@ def bench_windows(a):
         eval_bytes = B * algorithmic_bytes(N, R, H, W, dense)
         roof = dict(dominant)
         roof.update({'bound': 'hbm',
-                     'bound_note': 'priced against HBM as the contract asks; the kernels are NOT HBM-bound at these sizes: k_splat is bound by the '
-                                   'LDS atomic unit (ablation: deleting its arithmetic leaves its time unchanged), k_gather by VALU issue '
-                                   '(profiles/r02/splat_bound_experiment.txt, DESIGN.md section 4.2)',
+                     'bound_note': 'priced against HBM as the contract asks; the kernels are NOT HBM-bound at these sizes: both event kernels are bound by '
+                                   'VALU issue (round-3 ablation: k_splat without its LDS atomics 93.1 of 94.0 us, without its tap arithmetic 83.3; '
+                                   'profiles/r03/splat_bound_r03.txt, DESIGN.md section 4.2)',
                      'event_kernels': kern,
                      'lds_atomic_lane_ops_per_clk_per_cu': (9.0 * B * N * R / (kern['k_splat']['avg_launch_ms'] * 1e-3) / 256 / 2.4e9)
                      if kern['k_splat']['avg_launch_ms'] > 0 else 0.0,
-                     'lds_atomic_peak_lane_ops_per_clk_per_cu': [5.9, 7.4],
+                     'lds_atomic_peak_lane_ops_per_clk_per_cu': [7.2, 11.4],
                      'lds_atomic_note': '9 ds_add_u32 per warped event; peak = tools/lds_atomic_bench2.hip with the splat\'s own tap pattern at a 64-word '
                                         'row pitch: random columns, 32 distinct columns per half-wave (profiles/r03/lds_bank_pitch.txt); the kernel '
                                         'is VALU-bound, so this rate is what its arithmetic leaves room for, not what the LDS could do'})

@@ -71,6 +71,8 @@ struct eincm_ctx {
     // third list: the segments the 2-DoF gather walks, on the SPLAT's copy of the events (it has no per-pixel accumulators, so the
     // time-ordered copy serves it, and it wants shorter segments than the theta-grid gather does: round-2 tuning)
     Item* d_items_2 = nullptr; int32_t* d_order_2 = nullptr; int32_t* d_win_item0_2 = nullptr;
+    int pitch_policy = 0;          // the staged batch is in the regime where the bank-aligned LDS pitch pays (set_windows_impl); eval_begin decides per evaluation
+    double tspan_s = 1.0, tspan_sh = 1.0, tspan_a = 1.0, tspan_2 = 1.0;   // time span (fraction of the window) the window capacity is sized for, per segment list (span_quantile)
     Item* d_items_sh = nullptr; int32_t* d_order_sh = nullptr; int n_items_sh = 0; int seg_sh_used = 0;   // the splat's SHORT list (8192) beside a 16384-event
                                                                        // one: a 2-DoF theta too large for the long segments' windows walks it (launch_forward)
     int n_items_2 = 0; int seg_2_used = 0;
@@ -179,6 +181,7 @@ struct eincm_ctx {
     int last_nparts = 0;           // how many StatParts per image the last evaluation wrote (k_stats vs k_stats_stream)
     // an evaluation split in two halves (eval_begin ... [caller may all-reduce the IWE stack] ... eval_end)
     struct { bool active = false; bool launched = false; EvalParams ep{}; int h = 0, w = 0; bool identity = false, want_grad = false, full_aux = false, div_grad = false;
+             bool pal_2 = false;                    // the 2-DoF gather's windows at the bank-aligned pitch in this evaluation
              bool splat_short = false;              // this evaluation's k_splat walks the short segment list (d_items_sh)
              bool host_asm = false;                 // scalar assembly and the 2-DoF gradient sum on the host (see h_g11)
              bool composed = false;                 // k_imstat + composing gather (host_assemble: the contrast energy rides in h_img)
@@ -649,6 +652,8 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
     // LDS window capacity for this evaluation: the host knows theta, hence the largest displacement a segment can see.
     // Small windows give 8 workgroups per CU; windows too small for the flow push taps onto the slow direct-to-HBM path.
     c->pend.splat_short = false;
+    c->pend.pal_2 = c->pitch_policy >= 2;            // (a pinned capacity, EINCM_WINCAP: the pitch as staged)
+    c->g.pitch_aligned = c->pitch_policy != 0 ? 1 : 0;
     if (!c->wincap_fixed) {
         double vmax = 0.0;
         const size_t nall = (size_t)g.B * nth;
@@ -656,42 +661,47 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
         if (c->theta_dev_in) vmax = (c->vmax_hint >= 0.0 && std::isfinite(c->vmax_hint)) ? c->vmax_hint : 1e9;      // unknown: the largest windows
         else if (stride == 1) { for (size_t i = 0; i < nall; ++i) { const double a = std::fabs(theta_host[i]); vmax = std::max(vmax, a <= 1.7e308 ? a : 0.0); } }   // (vectorises)
         else for (size_t i = 0; i < nall; i += stride) { const double a = std::fabs(theta_host[i]); if (a > vmax && std::isfinite(a)) vmax = a; }
-        // time span of a typical splat segment: seg_s events out of the average tile population
-        const double per_tile = (double)std::max<int64_t>(c->n_events, 1) / ((double)g.B * g.ntiles);
-        const double tspan = std::min(1.0, (double)c->seg_s_used / std::max(per_tile, 1.0));
-        // LDS holds pitch x height words per window, the pitch being the width rounded up to the 32 banks (win_pitch)
-        auto lds_words = [](double side_px) { const double sd = std::ceil(side_px); return std::ceil(sd / 32.0) * 32.0 * sd; };
+        // time span the splat's windows are sized for: what all but 3 % of the events' segments stay within (span_quantile; the mean tile
+        // would size them for the dense tiles alone and send the taps of the sparse ones, whose single segment spans the whole window, to HBM)
+        const double tspan = c->tspan_s;
+        // LDS holds pitch x height words per window, the pitch being the width, or the width rounded up to the 32 banks (win_pitch).
+        // The aligned pitch is taken where the batch is in its regime (pitch_policy) AND it does not push the window into a larger
+        // capacity class: its gain is a few per cent of bank conflicts, a class costs workgroups per CU (8 windows of 10^6 events whose
+        // theta needs 66-pixel windows: 96 x 66 words = the 6912 class, 5 workgroups per CU, 2-DoF gather 62 -> 68 us).
+        auto lds_words = [](bool pal, double side_px) { const double sd = std::ceil(side_px); return (pal ? std::ceil(sd / 32.0) * 32.0 : sd) * sd; };
+        static const int caps[] = {2304, 3072, 4608, 6912};      // 6912 keeps k_gather's LDS (window + accumulators + Theta tile) under 64 KiB
+        auto cap_of = [&](double need, int floor_k) { for (int k = floor_k; k < 4; ++k) if (need <= caps[k]) return caps[k]; return caps[3]; };
         double side = TS + 4 + vmax * tspan;
-        double need = lds_words(side);
+        const bool two_dof = h == 1 && w == 1 && !identity;
         // a 2-DoF theta whose spread over a long splat segment outgrows the largest window: the short list (half the time span); the taps
         // of a window that is too small go to HBM one by one (117 px per window: 1220 us on the long list, 544 us on the short one)
-        c->pend.splat_short = (h == 1 && w == 1 && !identity && c->n_items_sh > 0 && need > 6912.0);
-        if (c->pend.splat_short) {
-            side = TS + 4 + vmax * std::min(1.0, (double)c->seg_sh_used / std::max(per_tile, 1.0));
-            need = lds_words(side);
-        }
-        static const int caps[] = {2304, 3072, 4608, 6912};      // 6912 keeps k_gather's LDS (window + accumulators + Theta tile) under 64 KiB
-        int cap = caps[3];
-        for (int k = 0; k < 4; ++k) if (need <= caps[k]) { cap = caps[k]; break; }
+        c->pend.splat_short = (two_dof && c->n_items_sh > 0 && lds_words(false, side) > 6912.0);
+        if (c->pend.splat_short) side = TS + 4 + vmax * c->tspan_sh;
+        // Where a larger window costs no residency it is taken at once (a capacity is an allocation, the windows themselves stay as small
+        // as their segments need): the 2-DoF kernels hold nothing but the window in LDS, 4608 words = 18 KiB still gives the 8 workgroups
+        // of 4 waves a CU can hold; the theta-grid gather carries 32 KiB beside its window and runs 3 workgroups per CU up to 5461 words.
+        // The theta-grid splat (window + 16 KiB Theta tile) pays for capacity with workgroups per CU (6 / 5 / 4 / 3), so it takes what it needs.
+        const int floor_k = two_dof ? 2 : 0;
+        int cap = cap_of(lds_words(false, side), floor_k);
+        const bool pal_s = c->pitch_policy != 0 && lds_words(true, side) <= (double)cap;
         // long splat segments (EINCM_SEG_SPLAT > EINCM_CHUNK) keep a second, f32 window: 2 * cap * 4 B + the 16 KiB Theta tile must
         // stay within the 64 KiB of dynamic LDS a launch gets without an attribute
         if (c->seg_s_used > c->chunk) cap = std::min(cap, 4608);
         c->g.wincap = cap;
         c->g.winmaxw = std::max(40, (int)std::lround(std::sqrt((double)cap * 1.4)));
+        c->g.pitch_aligned = pal_s ? 1 : 0;
         // the gather's own list: longer segments see a longer time span, hence a larger displacement spread; a window too small for it
         // sends taps down the direct path, where a composed dL/dIWE costs three loads per tap
-        const double tspan_a = std::min(1.0, (double)c->seg_used / std::max(per_tile, 1.0));
-        const double side_a = TS + 4 + vmax * tspan_a;
-        int cap_a = caps[3];
-        for (int k = 0; k < 4; ++k) if (side_a * side_a <= caps[k]) { cap_a = caps[k]; break; }          // (the theta-grid gather's windows: pitch = width)
-        cap_a = std::max(cap_a, cap);
+        const double side_a = TS + 4 + vmax * c->tspan_a;
+        const int cap_a = cap_of(side_a * side_a, 2);          // (the theta-grid gather's windows: pitch = width)
         c->g.wincap_a = cap_a;
         c->g.winmaxw_a = std::max(40, (int)std::lround(std::sqrt((double)cap_a * 1.4)));
         // and the 2-DoF gather's list
-        const double tspan_2 = std::min(1.0, (double)c->seg_2_used / std::max(per_tile, 1.0));
-        const double side_2 = TS + 4 + vmax * tspan_2;
-        int cap_2 = caps[3];
-        for (int k = 0; k < 4; ++k) if (lds_words(side_2) <= caps[k]) { cap_2 = caps[k]; break; }
+        const double side_2 = TS + 4 + vmax * c->tspan_2;
+        const int cap_2 = cap_of(lds_words(false, side_2), 2);
+        // (the 2-DoF gather keeps pitch = width: at the aligned pitch it measured equal on the bench batch and 63 -> 68 us on another batch
+        // of the same shape, profiles/r03/pitch_by_shape.txt; EINCM_PITCH_ALIGNED=2 aligns it too)
+        c->pend.pal_2 = c->pitch_policy >= 2 && lds_words(true, side_2) <= (double)cap_2;
         c->wincap_2 = cap_2;
     }
     // 2-DoF theta with nothing but the contrast and correlation terms (every level above 0 of the reference's pyramid at its first
@@ -860,7 +870,7 @@ int eval_end_launch(eincm_ctx* c) {
                 const uint32_t* xy_g = direct11 ? c->d_xy : c->d_xy_g;
                 const double* t_g = direct11 ? c->d_t : c->d_t_g;
                 Geom gg = g;
-                if (direct11) { gg.wincap_a = c->wincap_2; gg.winmaxw_a = std::max(40, (int)std::lround(std::sqrt((double)c->wincap_2 * 1.4))); }
+                if (direct11) { gg.pitch_aligned = c->pend.pal_2 ? 1 : 0; gg.wincap_a = c->wincap_2; gg.winmaxw_a = std::max(40, (int)std::lround(std::sqrt((double)c->wincap_2 * 1.4))); }
                 // theta grids with the in-gather projection on big launches: one workgroup per segment for all reference times (k_gather, all_r)
                 static const int all_r_env = getenv("EINCM_GATHER_ALL_R") ? atoi(getenv("EINCM_GATHER_ALL_R")) : -1;
                 // (8 windows of 10^6 events at 16x16: 792 workgroups of 5 reference times each instead of 3960: 148 -> 135 us; one window:
@@ -1320,6 +1330,25 @@ void eincm_destroy(eincm_ctx* ctx) {
 }
 
 // xs_w / ys_w / ts_w / edges_w: one pointer per window (the caller's own arrays; nothing is concatenated on the host)
+// The fraction of a window's duration the segments of a list span, for the choice of the LDS window capacity (eval_begin): a tile of n events
+// is cut into ceil(n / seg) segments, each spanning about 1 / that of the time.  Not the mean: sparse tiles (sensor noise between the edges)
+// hold one segment that spans the WHOLE window, and their taps go to HBM one by one when the capacity follows the dense tiles (480x640
+// with 10^7 events at 16x16 theta: k_gather 110 -> 90 us with the larger windows).  Returned: the span that all but 3 % of the events stay within.
+static double span_quantile(const std::vector<int32_t>& tilecount, int seg, int64_t N)
+{
+    constexpr int K = 64;
+    int64_t by_nseg[K + 1] = {0};
+    for (const int32_t n : tilecount)
+        if (n > 0) by_nseg[std::min<int64_t>(((int64_t)n + seg - 1) / seg, K)] += n;
+    int64_t beyond = 0;
+    const int64_t allow = (int64_t)(0.03 * (double)N);
+    for (int k = 1; k <= K; ++k) {              // spans 1, 1/2, 1/3, ...
+        beyond += by_nseg[k];
+        if (beyond > allow) return 1.0 / k;
+    }
+    return 1.0 / K;
+}
+
 static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64_t* n_events, const int16_t* const* xs_w,
                             const int16_t* const* ys_w, const double* const* ts_w, const double* const* edges_w,
                             const double* edge_ts, uint32_t sw_flags) {
@@ -1370,13 +1399,21 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     // workgroup); its 2-DoF form shares a segment among up to four workgroups instead (gather_wg_events, k_gather's nparts).
     int seg = c->seg > 0 ? c->seg : 16384;
     c->gather_wg_events = 1e30;              // (k_gather's nparts: an experiment, EINCM_GATHER_PARTS)
-    int seg_2 = x_wg >= 4000.0 ? 16384 : (x_wg < 1000.0 ? 4096 : 8192);       // the 2-DoF gather's own list (round-2 tuning)
+    int seg_2 = (x_wg >= 4000.0 && (double)N / ((double)n_windows * g.ntiles) < 16384.0) ? 16384 : (x_wg < 1000.0 ? 4096 : 8192);   // (tiles of several segments: as seg_s below; 480x640 with 10^7 events 90 -> 82 us)       // the 2-DoF gather's own list (round-2 tuning)
     if (const char* e = getenv("EINCM_SEG_2DOF")) { const int v = atoi(e); if (v >= 64 && v <= MAX_SEG) seg_2 = v; }
     c->seg_2_used = seg_2;
     c->seg_used = seg;
     // (late round 3: k_splat is no longer bound by the LDS atomic unit, so its per-workgroup fixed work - 24 of 90 us on the 8-window
     // batch: window derivation and clear 14, flush 10 - shows: 16384-event segments there, 90.1 -> 85.2 us; 104 -> 100 us at 16x16)
-    int seg_s = c->seg_s > 0 ? c->seg_s : (x_wg >= 3000.0 ? 16384 : (x_wg >= 400.0 ? 8192 : 4096));     // (4 windows of 10^6 events: 52.4 -> 49.7 us; 2 windows: equal; 1: 18.8 vs 19.7 the other way)  one window at R = 1: 4096 (0.066 vs 0.075 ms per evaluation)
+    // ... but only where a tile holds about one such segment: with tiles of several segments (480x640, 10^7 events: 33 000 per tile) the long
+    // segments double the duration of EVERY workgroup and the kernel ends in a tail of few resident waves (k_splat 93 -> 137 us there).
+    const double per_tile = (double)N / ((double)n_windows * g.ntiles);
+    int seg_s = c->seg_s > 0 ? c->seg_s : (x_wg >= 3000.0 && per_tile < 16384.0 ? 16384 : (x_wg >= 400.0 ? 8192 : 4096));     // (4 windows of 10^6 events: 52.4 -> 49.7 us; 2 windows: equal; 1: 18.8 vs 19.7 the other way)  one window at R = 1: 4096 (0.066 vs 0.075 ms per evaluation)
+    // The bank-aligned LDS pitch (win_pitch) goes with the same regime - many resident windows, about one segment per tile: both event
+    // kernels 2 % faster on the bench batch; everywhere else pitch = width is the faster layout (profiles/r03/pitch_by_shape.txt: one
+    // window of 10^6 events 72 -> 62 us per evaluation, 2 x 3*10^6 143 -> 128, 480x640 with 5*10^6 173 -> 126, with 10^7 220 -> 184).
+    g.pitch_aligned = (x_wg >= 3000.0 && per_tile < 16384.0) ? 1 : 0;
+    if (const char* e = getenv("EINCM_PITCH_ALIGNED")) g.pitch_aligned = std::max(0, std::min(2, atoi(e)));      // 0: never, 1: k_splat where it costs no capacity class, 2: the 2-DoF gather too
     c->seg_s_used = seg_s;
     const bool sort_segments = getenv("EINCM_NO_SEGSORT") == nullptr;
     if (!c->chunk_fixed) c->chunk = std::max(4096, std::min(seg_s, MAX_CHUNK));     // single-chunk segments: no f32 commit pass
@@ -1662,6 +1699,11 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_items_2 = (int)items_2.size();
+    c->tspan_s = span_quantile(c->h_tilecount, seg_s, N);
+    c->tspan_sh = span_quantile(c->h_tilecount, 8192, N);
+    c->tspan_a = span_quantile(c->h_tilecount, seg, N);
+    c->tspan_2 = span_quantile(c->h_tilecount, seg_2, N);
+    c->pitch_policy = g.pitch_aligned;
     c->g = g; c->n_items = n_items_total; c->n_items_s = n_items_s_total; c->n_events = N;
     c->itembase_valid = !c->host_binning && n_items_total > 0 && n_items_s_total > 0;      // both tile scans ran on the device
     c->win_events.assign(n_events, n_events + n_windows);

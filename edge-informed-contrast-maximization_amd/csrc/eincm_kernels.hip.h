@@ -71,6 +71,7 @@ struct Geom {
     unsigned long long wmask; // bit b: window b takes part in this evaluation (eincm_loss_grad_masked: a lockstep solver's converged windows
                               // sit out; their workgroups leave at once and their outputs are not written).  Windows >= 64 always take part.
     int igx, nig;             // k_imgrad strips per image row / per image (IG_COLS x IG_ROWS pixels each): slots of g2parts and gmax
+    int pitch_aligned;        // LDS windows of the splat's event copy at a row pitch rounded up to the 32 banks (win_pitch)
 };
 
 __device__ __forceinline__ bool win_active(const Geom& g, int b) { return b >= 64 || ((g.wmask >> b) & 1ull) != 0ull; }
@@ -238,13 +239,17 @@ struct Window { int ox, oy, ww, wh; };
 // its row, and staging deals the events so that the 32 lanes of a half-wave come from 32 different source columns (k_spread): their
 // nine taps fall on 32 different banks.  tools/lds_atomic_bench2.hip: 11.4 ds_add_u32 lane-ops per clock and CU that way, 9.8 with a
 // +-1 column jitter on 30 % of the lanes, 7.2 with random columns (what a pitch equal to the width gives).
-__device__ __forceinline__ int win_pitch(int ww) { return (ww + 31) & ~31; }
+// The aligned pitch is a property of the staged batch (Geom::pitch_aligned, set_windows_impl): it pays where the windows are resident in
+// numbers and a tile holds about one segment (the bench batch: both event kernels 2 % faster), and costs where tiles hold several
+// segments' worth of events (480x640 with 10^7 events: k_splat 73 -> 84 us at equal LDS capacity; profiles/r03/pitch_by_shape.txt).
+__device__ __forceinline__ int win_pitch(const Geom& g, int ww) { return g.pitch_aligned ? ((ww + 31) & ~31) : ww; }
 
 // aligned: the window is stored at the bank-aligned pitch (the splat's copy of the events: k_splat and the 2-DoF gather); the theta-grid
 // gather walks the pixel-sorted copy, whose half-waves hold neighbouring pixels of two or three rows: there a pitch of 64 lets the rows
 // alias onto the same banks (146 -> 150 us), so it keeps pitch = width.
 __device__ __forceinline__ Window item_window(const Geom& g, const Item& it, const double* __restrict__ mm4, double tau, int wincap, int winmaxw,
-                                              bool aligned = true) {
+                                              bool aligned_list = true) {
+    const bool aligned = aligned_list && g.pitch_aligned != 0;
     const int tx = it.tile % g.tilesX, ty = it.tile / g.tilesX;
     const int x0 = tx * TS, y0 = ty * TS;
     const int x1 = min(x0 + TS, g.W) - 1, y1 = min(y0 + TS, g.H) - 1;
@@ -263,10 +268,10 @@ __device__ __forceinline__ Window item_window(const Geom& g, const Item& it, con
     int bx0 = x0 + (int)lo[0] - 2, bx1 = x1 + (int)hi[0] + 2;
     int by0 = y0 + (int)lo[1] - 2, by1 = y1 + (int)hi[1] + 2;
     int ww = bx1 - bx0 + 1, wh = by1 - by0 + 1;
-    if ((aligned ? win_pitch(ww) : ww) * wh > wincap || ww > winmaxw) {          // (LDS holds pitch x wh words)
+    if ((aligned ? win_pitch(g, ww) : ww) * wh > wincap || ww > winmaxw) {          // (LDS holds pitch x wh words)
         int nww = min(ww, winmaxw);
         if (aligned && nww >= 64) nww &= ~31;        // a clamped wide window: a whole number of 32-word bank rows, so that no LDS is pitch padding
-        const int nwh = min(wh, wincap / (aligned ? win_pitch(nww) : nww));
+        const int nwh = min(wh, wincap / (aligned ? win_pitch(g, nww) : nww));
         bx0 = (bx0 + bx1) / 2 - nww / 2;
         by0 = (by0 + by1) / 2 - nwh / 2;
         ww = nww; wh = nwh;
@@ -672,7 +677,7 @@ __global__ __launch_bounds__(NTH) void k_splat(Geom g, int n_items, int chunk, i
         wn = wins[(size_t)item * g.R + r];
     }
     const int nwin = wn.ww * wn.wh;
-    const int wp = MERGE ? wn.ww : win_pitch(wn.ww), wp4 = wp * 4, nlds = wp * wn.wh;     // LDS row pitch and words (win_pitch; the MERGE experiment walks the
+    const int wp = MERGE ? wn.ww : win_pitch(g, wn.ww), wp4 = wp * 4, nlds = wp * wn.wh;     // LDS row pitch and words (win_pitch; the MERGE experiment walks the
                                                                             // gather's list, whose window table is sized for pitch = width)
     const bool multi = MULTI != 0 && it.count > chunk;       // MULTI == 0: the commit logic in the loop folds away
     {   // clear the window(s), 16 B per lane
@@ -1741,7 +1746,7 @@ __global__ __launch_bounds__(NTH, (ALLR ? 6 : 1)) void k_gather(Geom g, int n_it
     } else {
         wn = wins[(size_t)item * g.R + r];
     }
-    int wp = (theta_mode == THETA_CONST) ? win_pitch(wn.ww) : wn.ww;      // LDS row pitch of the G window (see item_window)
+    int wp = (theta_mode == THETA_CONST) ? win_pitch(g, wn.ww) : wn.ww;      // LDS row pitch of the G window (see item_window)
     size_t img = ((size_t)it.win * g.R + r) * g.H * g.W;
     const float* __restrict__ Gi = G + img;
     const float* __restrict__ Ei = edges + img;

@@ -27,6 +27,7 @@ SWITCHES = [
     ({'EINCM_GATHER_PARTS': '2'}, '2-DoF gather segments shared by two workgroups'),
     ({'EINCM_HOST_BINNING': '1'}, 'host-side counting sort'),
     ({'EINCM_GATHER_ALL_R': '1'}, 'theta-grid gather: one workgroup per segment walks all reference times'),
+    ({'EINCM_PITCH_ALIGNED': '2'}, 'LDS windows of both 2-DoF event kernels at the bank-aligned row pitch (k_splat: the policy of a large batch, forced on a small one)'),
 ]
 
 
