@@ -86,6 +86,7 @@ SIGNATURES = [
     ('eincm_loss_grad_masked_async', C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_void_p, C.c_int]),
     ('eincm_loss_grad_masked', C.c_int, [_P, C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('eincm_get_host_profile', C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+    ('eincm_get_launch_policy', C.c_int, [_P, C.POINTER(C.c_double)]),
     ('eincm_get_timings_total', C.c_int, [_P, C.POINTER(Timings), C.POINTER(C.c_int64), C.c_int]),
     ('eincm_set_windows_ex', C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int16),
                                        C.POINTER(C.c_int16), _D, _D, _D, C.c_uint32]),

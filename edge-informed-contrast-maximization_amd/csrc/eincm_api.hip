@@ -71,6 +71,7 @@ struct eincm_ctx {
     // third list: the segments the 2-DoF gather walks, on the SPLAT's copy of the events (it has no per-pixel accumulators, so the
     // time-ordered copy serves it, and it wants shorter segments than the theta-grid gather does: round-2 tuning)
     Item* d_items_2 = nullptr; int32_t* d_order_2 = nullptr; int32_t* d_win_item0_2 = nullptr;
+    bool policy_evaluated = false; // an evaluation has chosen capacities since the last staging (eincm_get_launch_policy)
     int pitch_policy = 0;          // the staged batch is in the regime where the bank-aligned LDS pitch pays (set_windows_impl); eval_begin decides per evaluation
     double tspan_s = 1.0, tspan_sh = 1.0, tspan_a = 1.0, tspan_2 = 1.0;   // time span (fraction of the window) the window capacity is sized for, per segment list (span_quantile)
     Item* d_items_sh = nullptr; int32_t* d_order_sh = nullptr; int n_items_sh = 0; int seg_sh_used = 0;   // the splat's SHORT list (8192) beside a 16384-event
@@ -651,6 +652,7 @@ int eval_begin(eincm_ctx* c, const double* theta_host, int h, int w, const eincm
 
     // LDS window capacity for this evaluation: the host knows theta, hence the largest displacement a segment can see.
     // Small windows give 8 workgroups per CU; windows too small for the flow push taps onto the slow direct-to-HBM path.
+    c->policy_evaluated = true;
     c->pend.splat_short = false;
     c->pend.pal_2 = c->pitch_policy >= 2;            // (a pinned capacity, EINCM_WINCAP: the pitch as staged)
     c->g.pitch_aligned = c->pitch_policy != 0 ? 1 : 0;
@@ -1704,6 +1706,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     c->tspan_a = span_quantile(c->h_tilecount, seg, N);
     c->tspan_2 = span_quantile(c->h_tilecount, seg_2, N);
     c->pitch_policy = g.pitch_aligned;
+    c->policy_evaluated = false;
     c->g = g; c->n_items = n_items_total; c->n_items_s = n_items_s_total; c->n_events = N;
     c->itembase_valid = !c->host_binning && n_items_total > 0 && n_items_s_total > 0;      // both tile scans ran on the device
     c->win_events.assign(n_events, n_events + n_windows);
@@ -2270,6 +2273,19 @@ int eincm_get_host_profile(eincm_ctx* c, double* us, int64_t* n_evals, int reset
     for (int i = 0; i < EINCM_N_HOST_PHASES; ++i) us[i] = c->hp_us[i];
     *n_evals = c->hp_n;
     if (reset) { for (double& v : c->hp_us) v = 0.0; c->hp_n = 0; }
+    return EINCM_OK;
+}
+
+int eincm_get_launch_policy(eincm_ctx* c, double* out) {
+    if (!c || !out) return EINCM_ERR_ARG;
+    out[EINCM_LP_SEG_GATHER] = c->seg_used; out[EINCM_LP_SEG_SPLAT] = c->seg_s_used; out[EINCM_LP_SEG_GATHER_2DOF] = c->seg_2_used;
+    out[EINCM_LP_SEG_SPLAT_SHORT] = c->seg_sh_used; out[EINCM_LP_PITCH_POLICY] = c->pitch_policy;
+    out[EINCM_LP_SPAN_SPLAT] = c->tspan_s; out[EINCM_LP_SPAN_GATHER] = c->tspan_a; out[EINCM_LP_SPAN_GATHER_2DOF] = c->tspan_2;
+    const bool evaluated = c->policy_evaluated;
+    out[EINCM_LP_CAP_SPLAT] = evaluated ? c->g.wincap : 0; out[EINCM_LP_CAP_GATHER] = evaluated ? c->g.wincap_a : 0;
+    out[EINCM_LP_CAP_GATHER_2DOF] = evaluated ? c->wincap_2 : 0;
+    out[EINCM_LP_PITCH_ALIGNED] = evaluated ? ((c->g.pitch_aligned ? 1 : 0) | (c->pend.pal_2 ? 2 : 0)) : 0;
+    out[EINCM_LP_SPLAT_SHORT] = evaluated && c->pend.splat_short ? 1 : 0;
     return EINCM_OK;
 }
 

@@ -428,6 +428,16 @@ class Engine:
         self._check(self._lib.eincm_get_host_profile(self._ctx, us, C.byref(n), 1 if reset else 0))
         return dict(zip(('begin', 'launch', 'wait', 'collect'), (float(v) for v in us))), int(n.value)
 
+    LAUNCH_POLICY_NAMES = ('seg_gather', 'seg_splat', 'seg_gather_2dof', 'seg_splat_short', 'pitch_policy', 'span_splat', 'span_gather',
+                           'span_gather_2dof', 'cap_splat', 'cap_gather', 'cap_gather_2dof', 'pitch_aligned', 'splat_short')
+
+    def launch_policy(self):
+        """Diagnostic (eincm_get_launch_policy): segment lengths and pitch regime of the staged batch, window capacities of the last
+        evaluation.  No counterpart in the reference."""
+        out = (C.c_double * len(self.LAUNCH_POLICY_NAMES))()
+        self._check(self._lib.eincm_get_launch_policy(self._ctx, out))
+        return dict(zip(self.LAUNCH_POLICY_NAMES, (float(v) for v in out)))
+
     def set_timed_kernels(self, splat=True, gather=True):
         """timing='dominant' contexts: which event kernels carry HIP timing events from the next evaluation on."""
         self._check(self._lib.eincm_set_timed_kernels(self._ctx, 1 if splat else 0, 1 if gather else 0))

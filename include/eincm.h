@@ -23,9 +23,10 @@
 extern "C" {
 #endif
 
-#define EINCM_ABI_VERSION 5   /* 2: eincm_iwe_device_ptr hands out the u64 fixed-point accumulator of the IWE stack; 3: eincm_set_timed_kernels, eincm_set_windows_ptrs;
+#define EINCM_ABI_VERSION 6   /* 2: eincm_iwe_device_ptr hands out the u64 fixed-point accumulator of the IWE stack; 3: eincm_set_timed_kernels, eincm_set_windows_ptrs;
                                 * 4: eincm_loss_grad_masked, eincm_set_device_results / eincm_finish_launch / eincm_grad_device_ptr / eincm_finish_collect, eincm_get_host_profile;
-                               * 5: eincm_get_warped_events, eincm_loss_grad_device, eincm_loss_grad_masked_async, eincm_set_timing_period */
+                               * 5: eincm_get_warped_events, eincm_loss_grad_device, eincm_loss_grad_masked_async, eincm_set_timing_period;
+                               * 6: eincm_get_launch_policy */
 
 #define EINCM_OK               0
 #define EINCM_ERR_ARG         -1   /* bad argument (shape, null pointer, out-of-range event coordinate) */
@@ -234,6 +235,25 @@ int eincm_set_timing_period(eincm_ctx* ctx, int period);
 #define EINCM_HP_COLLECT 3
 #define EINCM_N_HOST_PHASES 4
 int eincm_get_host_profile(eincm_ctx* ctx, double* us /* EINCM_N_HOST_PHASES */, int64_t* n_evals, int reset);
+/* Diagnostic: how the staged batch is cut into work and how the last evaluation was launched (no counterpart in the reference; the
+ * numbers behind DESIGN.md section 4.2 "where those rules hold").  Staging decides the segment lengths and whether the batch is in
+ * the regime of the bank-aligned LDS pitch; every evaluation decides the LDS window capacities from max|theta| and the time span
+ * that all but 3 % of the events' segments stay within.  Entries of the last evaluation are 0 before the first one. */
+#define EINCM_LP_SEG_GATHER 0        /* events per segment: the theta-grid gather's list */
+#define EINCM_LP_SEG_SPLAT 1         /* ... k_splat's list */
+#define EINCM_LP_SEG_GATHER_2DOF 2   /* ... the 2-DoF gather's list */
+#define EINCM_LP_SEG_SPLAT_SHORT 3   /* ... k_splat's short list for very large 2-DoF theta (0: none was built) */
+#define EINCM_LP_PITCH_POLICY 4      /* 0: LDS windows at pitch = width; 1: k_splat's at the bank-aligned pitch where that costs no capacity class; 2: the 2-DoF gather's too */
+#define EINCM_LP_SPAN_SPLAT 5        /* fraction of a window's duration the capacity of k_splat's windows is sized for */
+#define EINCM_LP_SPAN_GATHER 6
+#define EINCM_LP_SPAN_GATHER_2DOF 7
+#define EINCM_LP_CAP_SPLAT 8         /* last evaluation: LDS window capacity in 32-bit words, k_splat */
+#define EINCM_LP_CAP_GATHER 9        /* ... theta-grid gather */
+#define EINCM_LP_CAP_GATHER_2DOF 10  /* ... 2-DoF gather */
+#define EINCM_LP_PITCH_ALIGNED 11    /* last evaluation: bit 0 k_splat, bit 1 the 2-DoF gather took the aligned pitch */
+#define EINCM_LP_SPLAT_SHORT 12      /* last evaluation: k_splat walked its short list */
+#define EINCM_N_LAUNCH_POLICY 13
+int eincm_get_launch_policy(eincm_ctx* ctx, double* out /* EINCM_N_LAUNCH_POLICY */);
 /* sums of the per-evaluation timings since the last reset, and how many evaluations they cover (a bench reads them once after
  * its timed loop instead of calling eincm_get_timings inside it) */
 int eincm_get_timings_total(eincm_ctx* ctx, eincm_timings* sum, int64_t* n_evals, int reset);
