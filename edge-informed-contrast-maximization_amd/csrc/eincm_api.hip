@@ -462,7 +462,7 @@ void launch_theta_image(eincm_ctx* c, int h, int w, bool identity, bool use_arg,
     const Geom& g = c->g;
     const bool ww = with_windows && c->itembase_valid;
     launch_timed(c, EINCM_STAGE_THETA, k_theta, dim3(g.ntiles, g.B), dim3(NT), 0, g, h, w, identity ? 1 : 0, use_arg ? 1 : 0, targ,
-                 theta_dev, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_Theta, c->d_tmm, c->d_edge_ts,
+                 theta_dev, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_tilerng, c->d_Theta, c->d_tmm, c->d_edge_ts,
                  c->n_items, c->d_items, ww ? c->d_itembase : nullptr, c->d_wins,
                  c->n_items_s, c->d_items_s, ww ? c->d_itembase_s : nullptr, c->d_wins_s);
     c->Theta_valid = true;

@@ -338,6 +338,7 @@ __device__ __forceinline__ uint32_t fix_u32(float a, float b) { return cvt_rpi(a
 // of k_project were that latency.  A tile touches the coarse rows [ilo, ilo + ni) and columns [jlo, jlo + nj); staged when both
 // fit RS_MAXC (theta grids up to ~100 cells per axis at the usual sensors; anything else keeps the direct path).
 constexpr int RS_MAXC = 24;
+struct TileRange { int ilo, ni, jlo, nj; };     // the coarse cells a tile's pixels have weight on (host: ensure_resample)
 struct ResampleTile {
     int ilo, ni, jlo, nj;
     bool staged;
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
         const double* __restrict__ AW,         // (W,w)
         const int2* __restrict__ rowtap,       // (H) [lo,hi) non-zero range of AH[y,:]
         const int2* __restrict__ coltap,       // (W)
+        const TileRange* __restrict__ tilerng, // (ntiles) the coarse cells under each tile (host: ensure_resample)
         double* __restrict__ Theta,            // (B,H,W,2)
         double* __restrict__ tmm,              // (B,ntiles,4) vxmin,vxmax,vymin,vymax
         // window tables of this tile's segments (both segment lists), filled here when itembase_* != nullptr: a workgroup knows its
@@ -417,9 +419,25 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
     double mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
     bool nan = false;
     ResampleTile rs{};
+    // A latency chain, not a throughput kernel (88 workgroups on a 256x336 sensor; 9.8 us of a 48 us evaluation there): every dependent
+    // round trip to memory counts.  The tile's cell range comes from the host's table instead of a min / max over the tap ranges (one
+    // round trip and two barriers less), and the segment ranges of the window tables below are fetched up front.
+    const int idx = b * g.ntiles + tile, last = g.B * g.ntiles - 1;
+    int a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (itembase_a != nullptr) {                    // uniform
+        a0 = itembase_a[idx]; a1 = (idx < last) ? itembase_a[idx + 1] : n_a;
+        b0 = itembase_b[idx]; b1 = (idx < last) ? itembase_b[idx + 1] : n_b;
+    }
     if (!identity) {
         const int tx0 = tx * TS, ty0 = ty * TS, tx1 = min(tx * TS + TS, g.W), ty1 = min(ty * TS + TS, g.H);
-        rs = stage_resample_ranges(RL, h, w, tx0, ty0, tx1, ty1, rowtap, coltap);
+        const TileRange q = tilerng[tile];
+        rs.ilo = q.ilo; rs.ni = q.ni; rs.jlo = q.jlo; rs.nj = q.nj;
+        rs.staged = rs.ni <= RS_MAXC && rs.nj <= RS_MAXC;
+        if (rs.staged) {                            // the tap ranges of the tile's rows and columns (stage_resample_weights' barrier covers them)
+            const int t = threadIdx.x;
+            if (t < TS) RL.rt[t] = (ty0 + t < ty1) ? rowtap[ty0 + t] : make_int2(h, 0);
+            else if (t < 2 * TS) RL.ct[t - TS] = (tx0 + t - TS < tx1) ? coltap[tx0 + t - TS] : make_int2(w, 0);
+        }
         if (rs.staged) {                            // theta is read once per cell and workgroup (it may live in pinned host memory)
             for (int k = threadIdx.x; k < rs.ni * rs.nj; k += NT) {
                 const int i = rs.ilo + k / rs.nj, j = rs.jlo + k % rs.nj;
@@ -503,9 +521,6 @@ __global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity
     if (itembase_a == nullptr) return;           // uniform: the caller fills the window tables elsewhere (k_theta_const / k_windows)
     __syncthreads();
     const double mm4[4] = {mm4s[0], mm4s[1], mm4s[2], mm4s[3]};
-    const int idx = b * g.ntiles + tile, last = g.B * g.ntiles - 1;
-    const int a0 = itembase_a[idx], a1 = (idx < last) ? itembase_a[idx + 1] : n_a;
-    const int b0 = itembase_b[idx], b1 = (idx < last) ? itembase_b[idx + 1] : n_b;
     const int na = (a1 - a0) * g.R, nb = (b1 - b0) * g.R;
     for (int k = threadIdx.x; k < na + nb; k += NT) {
         const bool first = k < na;
@@ -1628,7 +1643,6 @@ __host__ __device__ __forceinline__ int tv_shift(int H, int W) {
     return 61 - e;
 }
 constexpr int PG_MAXC = 6;        // coarse rows / columns under one 32x32 tile that k_gather's own projection handles (16x16 theta on 260x346: 4)
-struct TileRange { int ilo, ni, jlo, nj; };     // the coarse cells a tile's pixels have weight on (host: ensure_resample)
 
 // One 32x32 tile of a (H,W,2) image projected onto the theta cells, cells[i,j] += sum_{y,x} AH[y,i] AW[x,j] vals[y,x]  (the adjoint of
 // theta_utils.py:25-35 restricted to the tile), by the whole workgroup.  vals: the tile as double2 in LDS, already at the cells'
