@@ -461,10 +461,19 @@ void launch_theta_image(eincm_ctx* c, int h, int w, bool identity, bool use_arg,
                         bool with_windows) {
     const Geom& g = c->g;
     const bool ww = with_windows && c->itembase_valid;
-    launch_timed(c, EINCM_STAGE_THETA, k_theta, dim3(g.ntiles, g.B), dim3(NT), 0, g, h, w, identity ? 1 : 0, use_arg ? 1 : 0, targ,
-                 theta_dev, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_tilerng, c->d_Theta, c->d_tmm, c->d_edge_ts,
-                 c->n_items, c->d_items, ww ? c->d_itembase : nullptr, c->d_wins,
-                 c->n_items_s, c->d_items_s, ww ? c->d_itembase_s : nullptr, c->d_wins_s);
+#define THETA_ARGS(T_) dim3(g.ntiles, g.B), dim3(NT), 0, g, h, w, identity ? 1 : 0, use_arg ? 1 : 0, T_, \
+                 theta_dev, c->d_AH, c->d_AW, c->d_rowtap, c->d_coltap, c->d_tilerng, c->d_Theta, c->d_tmm, c->d_edge_ts, \
+                 c->n_items, c->d_items, ww ? c->d_itembase : nullptr, c->d_wins, \
+                 c->n_items_s, c->d_items_s, ww ? c->d_itembase_s : nullptr, c->d_wins_s
+    // the argument block is copied by value into the launch and again into the kernarg buffer: 4 KiB where theta fits (one window at 16x16)
+    if (!use_arg || (size_t)g.B * h * w * 2 <= (size_t)THETA_ARG_MID) {
+        ThetaArgMid mid;
+        if (use_arg) memcpy(mid.v, targ.v, (size_t)g.B * h * w * 2 * sizeof(double));
+        launch_timed(c, EINCM_STAGE_THETA, k_theta<ThetaArgMid>, THETA_ARGS(mid));
+    } else {
+        launch_timed(c, EINCM_STAGE_THETA, k_theta<ThetaArgBig>, THETA_ARGS(targ));
+    }
+#undef THETA_ARGS
     c->Theta_valid = true;
 }
 

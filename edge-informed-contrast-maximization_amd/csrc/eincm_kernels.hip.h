@@ -181,6 +181,8 @@ constexpr int THETA_ARG_MAX = 128;    // doubles of theta that ride in the kerne
 struct ThetaArg { double v[THETA_ARG_MAX]; };
 constexpr int THETA_ARG_BIG = 4096;   // k_theta alone takes up to 32 KiB of theta (16x16 grids of 8 windows) in its arguments: no read of pinned host memory
 struct ThetaArgBig { double v[THETA_ARG_BIG]; };
+constexpr int THETA_ARG_MID = 512;    // ... and a 4 KiB form for one window's 16x16 grid: the launch copies its arguments twice on the host (k_theta<TA>)
+struct ThetaArgMid { double v[THETA_ARG_MID]; };
 
 struct OutScal {                  // per-window result block written by k_final
     double value, mean_rel_corr, mean_rel_contrast, mean_rel_div, tv, tv_scale, nonfinite, _pad;
@@ -391,7 +393,8 @@ __device__ __forceinline__ void stage_resample_weights(ResampleLds& L, const Res
 // grid (ntiles, B).  identity: theta already is (H,W,2).  Not launched for 2-DoF theta unless somebody needs the Theta image
 // (k_theta_const fills the velocity bounds then).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity, int use_arg, ThetaArgBig targ,
+template <typename TA>                 // TA: ThetaArgBig or ThetaArgMid, the kernel-argument block theta rides in when use_arg
+__global__ __launch_bounds__(NT) void k_theta(Geom g, int h, int w, int identity, int use_arg, TA targ,
         const double* __restrict__ theta,      // (B,h,w,2)
         const double* __restrict__ AH,         // (H,h)
         const double* __restrict__ AW,         // (W,w)
