@@ -22,6 +22,7 @@ namespace eincm {
 
 constexpr int BIN_CHUNK = 1024;          // events per staging block
 constexpr int BIN_NT = 64;               // one wave per block: its LDS traffic is ordered, which the stable ranking relies on
+constexpr int BIN_TRIPS = BIN_CHUNK / BIN_NT;
 constexpr int BIN_MAX_TILES = 12288;     // LDS histogram capacity (48 KiB); larger sensors use the host path
 
 struct BinBlock { int32_t win, start, count, first_blk; };    // start: global index of the block's first event
@@ -33,12 +34,24 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_hist(Geom g, const BinBlock* __r
 {
     extern __shared__ uint32_t hist[];
     const BinBlock bb = blks[blockIdx.x];
+    // all of the block's events are fetched before the first one is used: the block is ONE wavefront walking BIN_TRIPS trips, and with
+    // the loads inside the loop every trip waited for its own round trip to memory (24 us for 1024 events)
+    uint32_t xy[BIN_TRIPS]; double tt[BIN_TRIPS];
+#pragma unroll
+    for (int k = 0; k < BIN_TRIPS; ++k) {
+        const int i = k * BIN_NT + (int)threadIdx.x;
+        xy[k] = 0u; tt[k] = 0.0;
+        if (i < bb.count) { const int e = bb.start + i; xy[k] = (uint32_t)(uint16_t)xs[e] | ((uint32_t)(uint16_t)ys[e] << 16); tt[k] = ts[e]; }
+    }
     for (int i = threadIdx.x; i < g.ntiles; i += BIN_NT) hist[i] = 0u;
     __syncthreads();
-    for (int i = threadIdx.x; i < bb.count; i += BIN_NT) {
+#pragma unroll
+    for (int k = 0; k < BIN_TRIPS; ++k) {
+        const int i = k * BIN_NT + (int)threadIdx.x;
+        if (i >= bb.count) continue;
         const int e = bb.start + i;
-        const int x = xs[e], y = ys[e];
-        const double t = ts[e];
+        const int x = (int16_t)(xy[k] & 0xffffu), y = (int16_t)(xy[k] >> 16);
+        const double t = tt[k];
         if (x < 0 || x >= g.W || y < 0 || y >= g.H) { atomicMin(&err[0], e); continue; }
         if (!(t - t == 0.0)) { atomicMin(&err[1], e); continue; }
         atomicAdd(&hist[(y / TS) * g.tilesX + (x / TS)], 1u);
@@ -98,39 +111,47 @@ __global__ __launch_bounds__(BIN_NT) void k_bin_scatter(Geom g, const BinBlock* 
                                                          const uint32_t* __restrict__ blockoff, const int32_t* __restrict__ tilebase,
                                                          uint32_t* __restrict__ ev_xy, double* __restrict__ ev_t)
 {
-    extern __shared__ uint32_t cnt[];            // events of each tile this block has placed so far
+    extern __shared__ uint32_t cnt[];            // where this block's next event of each tile goes: tile base + block offset + placed so far
     const BinBlock bb = blks[blockIdx.x];
     const int lane = threadIdx.x;
-    for (int i = lane; i < g.ntiles; i += BIN_NT) cnt[i] = 0u;
-    __builtin_amdgcn_wave_barrier();
     const uint32_t* off = blockoff + (size_t)blockIdx.x * g.ntiles;
     const int32_t* tb = tilebase + (size_t)bb.win * g.ntiles;
+    for (int i = lane; i < g.ntiles; i += BIN_NT) cnt[i] = (uint32_t)tb[i] + off[i];       // (one coalesced pass instead of two gathers per event)
+    __builtin_amdgcn_wave_barrier();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int i0 = 0; i0 < bb.count; i0 += BIN_NT) {          // wave-uniform trip count
-        const int i = i0 + lane;
-        const int e = bb.start + i;
-        int x = 0, y = 0; double t = 0.0; int tile = -1;
-        if (i < bb.count) {
-            x = xs[e]; y = ys[e]; t = ts[e];
-            // events outside the sensor / with a non-finite time were reported by k_bin_hist and are not placed
-            if (x >= 0 && x < g.W && y >= 0 && y < g.H && (t - t == 0.0)) tile = (y / TS) * g.tilesX + (x / TS);
+    uint32_t xy[BIN_TRIPS]; double tt[BIN_TRIPS];        // every trip's events up front (see k_bin_hist)
+#pragma unroll
+    for (int k = 0; k < BIN_TRIPS; ++k) {
+        const int i = k * BIN_NT + lane;
+        xy[k] = 0u; tt[k] = 0.0;
+        if (i < bb.count) { const int e = bb.start + i; xy[k] = (uint32_t)(uint16_t)xs[e] | ((uint32_t)(uint16_t)ys[e] << 16); tt[k] = ts[e]; }
+    }
+    const int nbits = 32 - __clz(max(g.ntiles - 1, 1));      // bits of a tile index
+#pragma unroll
+    for (int k = 0; k < BIN_TRIPS; ++k) {
+        if (k * BIN_NT >= bb.count) break;                   // wave-uniform
+        const int i = k * BIN_NT + lane;
+        const int x = (int16_t)(xy[k] & 0xffffu), y = (int16_t)(xy[k] >> 16);
+        const double t = tt[k];
+        int tile = -1;
+        // events outside the sensor / with a non-finite time were reported by k_bin_hist and are not placed
+        if (i < bb.count && x >= 0 && x < g.W && y >= 0 && y < g.H && (t - t == 0.0)) tile = (y / TS) * g.tilesX + (x / TS);
+        // stable rank: the lanes that share a tile, found bit by bit (a match-any in nbits ballots instead of one round per distinct
+        // tile of the wavefront: up to 64 rounds of LDS read-modify-write before), ordered by lane (= input order); the tile's running
+        // count advances once per trip, by the group's lowest lane, after every lane has read it
+        unsigned long long grp = __ballot(tile >= 0);
+        for (int bit = 0; bit < nbits; ++bit) {
+            const bool one = ((tile >> bit) & 1) != 0;
+            const unsigned long long bal = __ballot(one);
+            grp &= one ? bal : ~bal;
         }
-        // stable rank: lanes that share a tile are ordered by lane (= input order); the tile's running count advances once per group
-        unsigned long long todo = __ballot(tile >= 0);
-        uint32_t slot = 0u;
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int T = __shfl(tile, leader, 64);
-            const unsigned long long grp = __ballot(tile == T);
-            const uint32_t base = cnt[T];                        // every lane reads the same word before the leader updates it
-            if (tile == T) slot = base + (uint32_t)__popcll(grp & lt_mask);
-            __builtin_amdgcn_wave_barrier();
-            if (lane == leader) cnt[T] = base + (uint32_t)__popcll(grp);
-            __builtin_amdgcn_wave_barrier();
-            todo &= ~grp;
-        }
+        uint32_t slot = 0u, base = 0u;
+        if (tile >= 0) { base = cnt[tile]; slot = base + (uint32_t)__popcll(grp & lt_mask); }
+        __builtin_amdgcn_wave_barrier();
+        if (tile >= 0 && (grp & lt_mask) == 0ull) cnt[tile] = base + (uint32_t)__popcll(grp);
+        __builtin_amdgcn_wave_barrier();
         if (tile >= 0) {
-            const size_t pos = (size_t)tb[tile] + off[tile] + slot;
+            const size_t pos = slot;
             ev_xy[pos] = (uint32_t)(uint16_t)x | ((uint32_t)(uint16_t)y << 16);
             ev_t[pos] = t;
         }
@@ -211,7 +232,8 @@ struct SegLayout {                 // where the sorted event of rank s (0 <= s <
         return (c ? n0 : 0) + j * 256 + t;
     }
 };
-constexpr int SORT_NT = 256, SORT_NW = SORT_NT / 64, SORT_KEYS = TS * TS;
+constexpr int SORT_NT = 256, SORT_NW = SORT_NT / 64, SORT_KEYS = TS * TS, SORT_KEY_BITS = 10;
+static_assert(SORT_KEYS == 1 << SORT_KEY_BITS, "pixkey has SORT_KEY_BITS bits");
 __device__ __forceinline__ uint32_t pixkey(uint32_t xy) { return ((xy >> 11) & (31u << 5)) | (xy & 31u); }     // pixel inside the 32x32 tile (raster order)
 __global__ __launch_bounds__(SORT_NT) void k_segsort(int n_items, const Item* __restrict__ items,
                                                       const uint32_t* __restrict__ src_xy, const double* __restrict__ src_t,
@@ -252,24 +274,28 @@ __global__ __launch_bounds__(SORT_NT) void k_segsort(int n_items, const Item* __
         __syncthreads();
         // placement: a wave walks its quarter in input order; lanes of a step that share a key are ranked by lane
         const SegLayout L(n);
+        // (the next step's events are fetched before this step is ranked: the steps of a wave depend on each other through LDS only)
+        uint32_t nxy = 0u; double nt = 0.0;
+        if (lo + lane < hi) { nxy = src_xy[begin + lo + lane]; nt = src_t[begin + lo + lane]; }
         for (int i0 = lo; i0 < hi; i0 += 64) {                  // wave-uniform trip count
             const int i = i0 + lane;
             const bool valid = i < hi;
-            uint32_t xy = 0u; double t = 0.0; int key = -1;
-            if (valid) { xy = src_xy[begin + i]; t = src_t[begin + i]; key = (int)pixkey(xy); }
-            unsigned long long todo = __ballot(valid);
-            uint32_t rank = 0u;
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const int Kk = __shfl(key, leader, 64);
-                const unsigned long long grp = __ballot(key == Kk);
-                const uint32_t base = cnt[wv][Kk];                  // every lane reads the same word before the leader updates it
-                if (key == Kk) rank = base + (uint32_t)__popcll(grp & lt_mask);
-                __builtin_amdgcn_wave_barrier();
-                if (lane == leader) cnt[wv][Kk] = base + (uint32_t)__popcll(grp);
-                __builtin_amdgcn_wave_barrier();
-                todo &= ~grp;
+            const uint32_t xy = nxy; const double t = nt;
+            if (i + 64 < hi) { nxy = src_xy[begin + i + 64]; nt = src_t[begin + i + 64]; }
+            const int key = valid ? (int)pixkey(xy) : -1;
+            // the lanes that share a key, found bit by bit (SORT_KEYS = 2^10: ten ballots instead of one LDS round per distinct key of the step)
+            unsigned long long grp = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < SORT_KEY_BITS; ++bit) {
+                const bool one = ((key >> bit) & 1) != 0;
+                const unsigned long long bal = __ballot(one);
+                grp &= one ? bal : ~bal;
             }
+            uint32_t rank = 0u, base = 0u;
+            if (valid) { base = cnt[wv][key]; rank = base + (uint32_t)__popcll(grp & lt_mask); }      // every lane reads before a leader updates
+            __builtin_amdgcn_wave_barrier();
+            if (valid && (grp & lt_mask) == 0ull) cnt[wv][key] = base + (uint32_t)__popcll(grp);
+            __builtin_amdgcn_wave_barrier();
             if (valid) {
                 const int pos = L.position((int)rank);
                 dst_xy[begin + pos] = xy;
