@@ -1541,9 +1541,11 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             HIPCHK(c, hipMemcpyAsync(c->h_win_item0.data(), c->d_win_item0, (size_t)n_windows * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
             // second segmentation of the same binned events for k_splat
             hipLaunchKernelGGL(k_bin_tilescan, dim3(1), dim3(1024), 0, c->stream, M, seg_s, c->d_tilecount, c->d_tilebase, c->d_itembase_s, c->d_bin_misc);
-            HIPCHK(c, hipMemcpyAsync(misc, c->d_bin_misc, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            n_items_s_total = misc[1];
+            {   // its total is not read back (a synchronisation per staging): the host repeats the arithmetic on the tile populations it holds
+                std::vector<int32_t> lens_s;
+                segment_lengths(c->h_tilecount, seg_s, lens_s);
+                n_items_s_total = (int)lens_s.size();
+            }
             if (n_items_s_total > c->max_items) return fail(c, EINCM_ERR_ARG, "internal: %d splat segments exceed capacity", n_items_s_total);
             hipLaunchKernelGGL(k_items, dim3((M + 255) / 256), dim3(256), 0, c->stream, g, seg_s, c->d_tilecount, c->d_tilebase, c->d_itembase_s, c->d_items_s);
             if (n_items_s_total > 0)
