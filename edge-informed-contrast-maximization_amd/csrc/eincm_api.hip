@@ -1710,6 +1710,13 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
             c->n_items_sh = (int)items_sh.size(); c->seg_sh_used = 8192;
         }
     }
+    if (n_items_total > 0 && !c->host_binning) {     // event mask + most events on one source pixel, per tile from its LDS histogram
+        HIPCHK(c, hipMemsetAsync(c->d_cntmax, 0, (size_t)n_windows * sizeof(unsigned), c->stream));       // (before the synchronisation below: one per staging fewer)
+        hipLaunchKernelGGL(k_tile_counts, dim3(g.ntiles, n_windows), dim3(NT), 0, c->stream, g, c->d_tilebase, c->d_tilecount, c->d_xy,
+                           c->d_mask, c->d_cntmax);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(cntmax_h.data(), c->d_cntmax, (size_t)n_windows * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_items_2 = (int)items_2.size();
     c->tspan_s = span_quantile(c->h_tilecount, seg_s, N);
@@ -1721,14 +1728,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     c->g = g; c->n_items = n_items_total; c->n_items_s = n_items_s_total; c->n_events = N;
     c->itembase_valid = !c->host_binning && n_items_total > 0 && n_items_s_total > 0;      // both tile scans ran on the device
     c->win_events.assign(n_events, n_events + n_windows);
-    if (c->n_items > 0 && !c->host_binning) {     // event mask + most events on one source pixel, per tile from its LDS histogram
-        HIPCHK(c, hipMemsetAsync(c->d_cntmax, 0, (size_t)n_windows * sizeof(unsigned), c->stream));
-        hipLaunchKernelGGL(k_tile_counts, dim3(g.ntiles, n_windows), dim3(NT), 0, c->stream, g, c->d_tilebase, c->d_tilecount, c->d_xy,
-                           c->d_mask, c->d_cntmax);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(cntmax_h.data(), c->d_cntmax, (size_t)n_windows * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    } else if (c->n_items > 0) {
+    if (c->n_items > 0 && c->host_binning) {
         hipLaunchKernelGGL(k_mask, dim3(std::min(c->n_items, 2048)), dim3(NT), 0, c->stream, g, c->d_items, c->n_items, c->d_xy, c->d_mask);
         HIPCHK(c, hipGetLastError());
     }
