@@ -68,11 +68,16 @@ __global__ void k_bin_scan(Geom g, const int32_t* __restrict__ win_blk, uint32_t
     if (idx >= g.B * g.ntiles) return;
     const int b = idx / g.ntiles, tile = idx % g.ntiles;
     uint32_t run = 0;
-    for (int k = win_blk[b]; k < win_blk[b + 1]; ++k) {
-        uint32_t* p = blockhist + (size_t)k * g.ntiles + tile;
-        const uint32_t v = *p;
-        *p = run;
-        run += v;
+    // sixteen blocks per trip, all loads before the first store: one load -> store -> load chain per block made this pass 280 us at 10^6
+    // events (977 blocks per window) and 2.8 ms at 10^7, a quarter of staging
+    const int k0 = win_blk[b], k1 = win_blk[b + 1];
+    for (int k = k0; k < k1; k += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = (k + j < k1) ? blockhist[(size_t)(k + j) * g.ntiles + tile] : 0u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (k + j < k1) { blockhist[(size_t)(k + j) * g.ntiles + tile] = run; run += v[j]; }
     }
     tilecount[idx] = (int32_t)run;
 }
