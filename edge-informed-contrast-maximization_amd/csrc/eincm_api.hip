@@ -1440,6 +1440,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     std::vector<unsigned> cntmax_h((size_t)n_windows, 0u);
     std::vector<double> dtmax_h((size_t)n_windows, 0.0);
     std::vector<int32_t> item0_h;                  // host path only
+    bool edge_ts_uploaded = false;
     if (!c->host_binning) {
         // ---- device path: counting sort by (window, source tile) on the GPU (eincm_binning.hip.h) ----
         std::vector<BinBlock> blks;
@@ -1535,6 +1536,7 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
                 hipLaunchKernelGGL(k_spread, dim3(M, SPREAD_Y), dim3(256), 0, c->stream, g, c->d_tilecount, c->d_tilebase, c->d_xy, c->d_t);
             // per window: first segment and max |t - tau| (needs the segment time ranges and the FIRST segmentation's itembase)
             HIPCHK(c, hipMemcpyAsync(c->d_edge_ts, edge_ts, (size_t)n_windows * n_refs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            edge_ts_uploaded = true;
             hipLaunchKernelGGL(k_win_consts, dim3(n_windows), dim3(NT), 0, c->stream, g, n_items_total, c->d_items, c->d_itembase, c->d_edge_ts,
                                c->d_win_item0, c->d_dtmax);
             HIPCHK(c, hipMemcpyAsync(dtmax_h.data(), c->d_dtmax, (size_t)n_windows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1677,7 +1679,8 @@ static int set_windows_impl(eincm_ctx* c, int n_windows, int n_refs, const int64
     HIPCHK(c, hipMemcpyAsync(c->d_edges, ef.data(), ef.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));     // host vectors go out of scope
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_edge_ts, edge_ts, (size_t)n_windows * n_refs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (!edge_ts_uploaded)
+        HIPCHK(c, hipMemcpyAsync(c->d_edge_ts, edge_ts, (size_t)n_windows * n_refs * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_mask, 0, (size_t)n_windows * img, c->stream));
     std::vector<Item> items_2;
     {   // the 2-DoF gather's segment list (splat copy of the events): generated on the host from the tile populations
